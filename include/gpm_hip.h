@@ -1,0 +1,171 @@
+/*
+ * gpm_hip.h -- C ABI of the MI355X match-search library (libgpm_hip.so).
+ *
+ * The reference has no plugin or FFI interface; its search is one C call,
+ * findMatches(graph, pattern, nodeProcMap, rank) (reference:
+ * src/gpm-par.c:245, called at :628), whose results leave the worker as one
+ * message of P+1 ints per match (reference: src/gpm-par.c:181) that rank 0
+ * turns into one output line (reference: src/gpm-par.c:608-613).  This
+ * header is that seam as a C ABI: plain pointers and sizes, no C++ or
+ * framework types.  A C host (mpi_amd/host/gpm-par.c) calls it exactly where
+ * the reference calls findMatches.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a non-zero GPM_E* code on
+ *     error; gpm_hip_last_error() returns a message for the calling thread;
+ *   - the caller owns every host pointer it passes; device memory belongs to
+ *     the context and is released by gpm_hip_destroy();
+ *   - vertex ids are 0-based at this boundary (the text format's ids minus 1);
+ *   - the library never calls back into host code from device threads; the
+ *     row sink of gpm_hip_search() runs on the calling host thread;
+ *   - one context may drive several GPUs of one node; calls on one context
+ *     must not overlap.
+ */
+#ifndef GPM_HIP_H_
+#define GPM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPM_MAX_PATTERN 10 /* reference: MAX_MATCH_SIZE, src/gpm-par.c:13 */
+#define GPM_MAX_CONS 9     /* a level has at most P-1 matched neighbours */
+
+enum {
+    GPM_OK = 0,
+    GPM_EINVAL = 1,   /* bad argument (shape, range, NULL) */
+    GPM_ENODEV = 2,   /* no usable GPU / HIP runtime error at set-up */
+    GPM_ENOMEM = 3,   /* host or device allocation failed */
+    GPM_ERUNTIME = 4, /* HIP error during a call */
+    GPM_ESTATE = 5,   /* call order violated (e.g. search before upload) */
+    GPM_ESINK = 6     /* the row sink asked to stop */
+};
+
+typedef struct gpm_ctx gpm_ctx;
+
+/*
+ * Matching plan: the order in which pattern vertices are bound and, for each
+ * level, where candidates come from and what they must satisfy.  It restates
+ * what the reference derives on the fly from Graph.ordering / Graph.parents
+ * (reference: src/graph.c:7-36, used at src/gpm-par.c:186-206) and from the
+ * pattern rows in checkNodeMatches (reference: src/gpm-par.c:88-112).
+ *
+ * Level 0 binds order[0] to a root vertex.  Level k >= 1 binds order[k]:
+ *   candidates   = N_dir(m[src_level[k]]) walked WITH multiplicity, where
+ *                  dir = src_dir[k] (0 = out-list, 1 = in-list);
+ *   accepted iff   c is not already in the partial match, and
+ *                  c is in N_{cons_dir[k][j]}(m[cons_level[k][j]]) for every j, and
+ *                  c >  m[lower_level[k][j]] for every j  (symmetry breaking), and
+ *                  c <  m[upper_level[k][j]] for every j  (symmetry breaking), and
+ *                  label/degree filters hold (see below).
+ * "m[i]" is the data vertex bound at level i.  The order relation of the
+ * symmetry-breaking bounds is the library's internal vertex order (any strict
+ * total order gives the same result set); such bounds are only legal on a data
+ * graph without duplicate arcs, and the number of automorphic images each
+ * reported match stands for is n_aut (1 when no bounds are used).
+ */
+typedef struct {
+    int32_t n_levels;                 /* P, 1..GPM_MAX_PATTERN */
+    int32_t order[GPM_MAX_PATTERN];   /* pattern vertex (0-based) bound at level k */
+    int32_t src_level[GPM_MAX_PATTERN];
+    int32_t src_dir[GPM_MAX_PATTERN];
+    int32_t n_cons[GPM_MAX_PATTERN];
+    int32_t cons_level[GPM_MAX_PATTERN][GPM_MAX_CONS];
+    int32_t cons_dir[GPM_MAX_PATTERN][GPM_MAX_CONS];
+    int32_t n_lower[GPM_MAX_PATTERN];
+    int32_t lower_level[GPM_MAX_PATTERN][GPM_MAX_CONS];
+    int32_t n_upper[GPM_MAX_PATTERN];
+    int32_t upper_level[GPM_MAX_PATTERN][GPM_MAX_CONS];
+    /* filters per level; label < 0 means "any"; degrees count distinct
+     * non-self neighbours the data vertex must at least have */
+    int32_t label[GPM_MAX_PATTERN];
+    int32_t min_out_deg[GPM_MAX_PATTERN];
+    int32_t min_in_deg[GPM_MAX_PATTERN];
+    /* automorphisms used to expand each reported match into all its images:
+     * aut[i*P + v] = image of pattern vertex v under automorphism i; the
+     * identity comes first.  n_aut == 1 and aut == NULL when unused. */
+    uint64_t n_aut;
+    const int8_t *aut;
+} gpm_plan;
+
+typedef struct {
+    int32_t n;           /* vertices */
+    int64_t m_out;       /* arcs */
+    int32_t symmetric;   /* in-lists equal out-lists as sets */
+    int32_t simple;      /* no duplicate arcs and no self loops */
+    int32_t max_out_deg, max_in_deg;
+    int32_t has_labels;
+} gpm_graph_info;
+
+typedef struct {
+    uint64_t matches;                      /* embeddings (all automorphic images) */
+    uint64_t canonical;                    /* matches before multiplying by n_aut */
+    uint64_t rows_in[GPM_MAX_PATTERN];     /* partial matches of length k+1 that were extended */
+    uint64_t alg_bytes;                    /* merge-model bytes of the work done */
+    uint64_t tail_alg_bytes;               /* part of alg_bytes done by the fused intersection kernel */
+    double   ms_total;                     /* wall time of the last search */
+    double   ms_tail_kernel;               /* summed device time of the intersection kernel */
+    double   ms_extend_kernel;             /* summed device time of the level-extension kernel */
+    uint64_t tail_launches, extend_launches;
+    uint64_t chunks[8];                    /* root chunks taken by each GPU of the context */
+} gpm_stats;
+
+/* Row sink: called on the calling host thread with `nrows` complete matches,
+ * `ncols` = P ints each, in pattern-vertex order, 1-based ids (the numbers the
+ * reference prints, reference: writeMatch src/gpm-par.c:71-77).  Return 0 to
+ * continue, non-zero to stop the search (gpm_hip_search then returns
+ * GPM_ESINK). */
+typedef int (*gpm_row_sink)(void *user, const int32_t *rows, uint64_t nrows, int32_t ncols);
+
+const char *gpm_hip_last_error(void);
+
+/* Number of GPUs the runtime sees (0 when there is none). */
+int gpm_hip_device_count(void);
+
+/* Create a context on `ngpus` devices.  devices == NULL selects 0..ngpus-1.
+ * Replaces MPI_Init / Comm_size / Comm_rank (reference: src/gpm-par.c:636-639). */
+int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out);
+void gpm_hip_destroy(gpm_ctx *ctx);
+
+/* Copy the data graph to every GPU of the context as CSR (replaces the
+ * scatter of the graph over ranks, reference: distribiuteGraph / gatherGraph /
+ * transpose, src/gpm-par.c:394-553).  Lists must be sorted ascending;
+ * duplicates are kept.  in_off/in_adj may be NULL when the graph is symmetric
+ * (the in-CSR then aliases the out-CSR).  labels may be NULL. */
+int gpm_hip_upload_graph(gpm_ctx *ctx, int32_t n,
+                         const int64_t *out_off, const int32_t *out_adj,
+                         const int64_t *in_off, const int32_t *in_adj,
+                         const uint8_t *labels);
+int gpm_hip_graph_info(const gpm_ctx *ctx, gpm_graph_info *info);
+
+/* Install the plan (replaces the pattern broadcast, reference:
+ * distribiutePattern / gatherPattern, src/gpm-par.c:342-392). */
+int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *plan);
+
+/* Share the root-chunk cursor with other processes on this node (one context
+ * per process, one GPU each): `cursor` points to a zero-initialised 64-bit
+ * word in memory all of them map.  NULL (default) = private cursor.  Together
+ * with gpm_hip_set_roots this replaces vertex ownership (reference:
+ * assignNodesToProcesses, src/gpm-par.c:300-340). */
+int gpm_hip_set_cursor(gpm_ctx *ctx, volatile uint64_t *cursor);
+
+/* Restrict roots to [lo, hi) of the library's root order (0 <= lo <= hi <= n);
+ * default is all n.  Used for sharding tests. */
+int gpm_hip_set_roots(gpm_ctx *ctx, int64_t lo, int64_t hi);
+
+/* Run the search (replaces findMatches on the workers and the receive loop on
+ * rank 0, reference: src/gpm-par.c:245-262 and :602-626).  count_only != 0:
+ * only count; sink may be NULL.  Otherwise every match is delivered to `sink`
+ * exactly once, in unspecified order.  *total receives this context's number
+ * of embeddings. */
+int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, void *user, uint64_t *total);
+
+int gpm_hip_stats(const gpm_ctx *ctx, gpm_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

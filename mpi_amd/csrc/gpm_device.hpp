@@ -1,0 +1,142 @@
+// Device-side views and helpers shared by the gpm kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GPM_WAVE 64
+#define GPM_MAXP 10
+#define GPM_MAXC 9
+
+// CSR of the data graph as it sits in HBM.  Vertices are renumbered by
+// ascending total degree, so "id order" is "degree order": the part of a
+// sorted list above its owner (mid..end) holds only neighbours of equal or
+// higher degree, which keeps the lists walked under ordering bounds short.
+struct GraphView {
+    int32_t n;
+    const int64_t *off[2];  // [0] out-CSR, [1] in-CSR (aliases [0] on a symmetric graph)
+    const int32_t *adj[2];
+    const int64_t *mid[2];  // first position in v's list with id > v
+    const uint8_t *label;   // by internal id, or nullptr
+};
+
+enum { PART_FULL = 0, PART_ABOVE = 1, PART_BELOW = 2 };
+
+// One level of the matching plan, flattened for the device.
+struct LevelPlan {
+    int8_t src_level, src_dir, src_part;
+    int8_t n_cons, n_lower, n_upper;
+    int8_t cons_level[GPM_MAXC], cons_dir[GPM_MAXC], cons_part[GPM_MAXC];
+    int8_t lower_level[GPM_MAXC], upper_level[GPM_MAXC];
+    int8_t lower_is_src;  // the only lower bound is the source owner (range = PART_ABOVE, no search)
+    int32_t label, min_out, min_in;
+};
+
+struct PlanView {
+    int32_t P;
+    int8_t order[GPM_MAXP];  // pattern vertex bound at each level
+    LevelPlan lv[GPM_MAXP];
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (GPM_WAVE - 1); }
+
+// First position in [b, e) of a sorted array whose value is >= key.
+__device__ __forceinline__ int64_t lower_bound_g(const int32_t *a, int64_t b, int64_t e, int32_t key) {
+    while (b < e) {
+        int64_t m = b + ((e - b) >> 1);
+        if (a[m] < key) b = m + 1;
+        else e = m;
+    }
+    return b;
+}
+
+__device__ __forceinline__ bool contains_g(const int32_t *a, int64_t b, int64_t e, int32_t key) {
+    int64_t p = lower_bound_g(a, b, e, key);
+    return p < e && a[p] == key;
+}
+
+// Same on an LDS-resident sorted array with 32-bit positions.
+__device__ __forceinline__ int lower_bound_s(const int32_t *a, int b, int e, int32_t key) {
+    while (b < e) {
+        int m = (b + e) >> 1;
+        if (a[m] < key) b = m + 1;
+        else e = m;
+    }
+    return b;
+}
+
+__device__ __forceinline__ void list_range(const GraphView &g, int dir, int part, int32_t v, int64_t &b, int64_t &e) {
+    b = g.off[dir][v];
+    e = g.off[dir][v + 1];
+    if (part == PART_ABOVE) b = g.mid[dir][v];
+    else if (part == PART_BELOW) e = g.mid[dir][v];
+}
+
+// Candidate range of one level for the partial match m: the source list cut
+// down by the ordering bounds (c > every lower bound, c < every upper bound).
+__device__ __forceinline__ void source_range(const GraphView &g, const LevelPlan &lv, const int32_t *m, int64_t &b,
+                                             int64_t &e) {
+    list_range(g, lv.src_dir, lv.src_part, m[lv.src_level], b, e);
+    if (lv.n_lower && !lv.lower_is_src) {
+        int32_t lo = m[lv.lower_level[0]];
+        for (int j = 1; j < lv.n_lower; ++j) lo = max(lo, m[lv.lower_level[j]]);
+        b = lower_bound_g(g.adj[lv.src_dir], b, e, lo + 1);
+    }
+    if (lv.n_upper) {
+        int32_t hi = m[lv.upper_level[0]];
+        for (int j = 1; j < lv.n_upper; ++j) hi = min(hi, m[lv.upper_level[j]]);
+        e = lower_bound_g(g.adj[lv.src_dir], b, e, hi);
+    }
+}
+
+// Per-vertex filters of a level: label and minimum degrees.
+__device__ __forceinline__ bool vertex_ok(const GraphView &g, const LevelPlan &lv, int32_t c) {
+    if (lv.label >= 0 && g.label[c] != (uint8_t)lv.label) return false;
+    if (lv.min_out > 0 && g.off[0][c + 1] - g.off[0][c] < lv.min_out) return false;
+    if (lv.min_in > 0 && g.off[1][c + 1] - g.off[1][c] < lv.min_in) return false;
+    return true;
+}
+
+// Full acceptance test of candidate c at a level whose partial match is
+// m[0..k): not already used, vertex filters, and membership in the list of
+// every other bound pattern neighbour.  skip_cons >= 0 leaves that
+// constraint out and tests the source list instead (used when the caller
+// walks that constraint's list rather than the source list).
+__device__ __forceinline__ bool accept(const GraphView &g, const LevelPlan &lv, const int32_t *m, int k, int32_t c,
+                                       int skip_cons = -1) {
+    for (int t = 0; t < k; ++t)
+        if (m[t] == c) return false;
+    if (!vertex_ok(g, lv, c)) return false;
+    for (int j = 0; j < lv.n_cons; ++j) {
+        int64_t b, e;
+        if (j == skip_cons) list_range(g, lv.src_dir, lv.src_part, m[lv.src_level], b, e);
+        else list_range(g, lv.cons_dir[j], lv.cons_part[j], m[lv.cons_level[j]], b, e);
+        const int32_t *a = g.adj[j == skip_cons ? lv.src_dir : lv.cons_dir[j]];
+        if (!contains_g(a, b, e, c)) return false;
+    }
+    return true;
+}
+
+// Merge-model bytes of extending one partial match of length k at this
+// level: the match itself plus one pass over every operand list, each list
+// counted at its ordered length.
+__device__ __forceinline__ uint64_t level_bytes(const GraphView &g, const LevelPlan &lv, const int32_t *m, int k) {
+    int64_t b, e;
+    list_range(g, lv.src_dir, lv.src_part, m[lv.src_level], b, e);
+    uint64_t bytes = 4ull * (uint64_t)k + 4ull * (uint64_t)(e - b);
+    for (int j = 0; j < lv.n_cons; ++j) {
+        list_range(g, lv.cons_dir[j], lv.cons_part[j], m[lv.cons_level[j]], b, e);
+        bytes += 4ull * (uint64_t)(e - b);
+    }
+    return bytes;
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, GPM_WAVE);
+    return v;  // valid in lane 0
+}
+
+// Orders a wave's own LDS stores before its later LDS loads.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}

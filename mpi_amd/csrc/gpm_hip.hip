@@ -1,0 +1,949 @@
+// libgpm_hip.so -- host side of the MI355X match search: the C ABI declared in
+// include/gpm_hip.h, graph preparation in HBM, and the chunked level-by-level
+// driver that launches the kernels of gpm_kernels.hpp.
+#include <cstring>  // before rocprim: its texture iterator calls host memset
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/gpm_hip.h"
+#include "gpm_kernels.hpp"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? GPM_ENOMEM : GPM_ERUNTIME, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                    \
+    } while (0)
+
+extern "C" const char *gpm_hip_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+
+enum {  // slots of the per-device counter block (unsigned long long each)
+    CTR_LEVEL0 = 0,   // [0, GPM_MAXP): rows produced into level k's frontier
+    CTR_MATCHES = 16, // matches counted by the level-extension kernel
+    CTR_BYTES = 17,   // merge-model bytes summed by k_ranges
+    CTR_TAIL_MATCHES = 18,
+    CTR_TAIL_BYTES = 19,
+    CTR_EMIT = 20,
+    CTR_COUNT = 32
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kind;  // 0 = tail kernel, 1 = extend kernel
+};
+
+struct DevState {
+    int dev = -1;
+    hipStream_t stream = nullptr;
+    // graph
+    int32_t n = 0;
+    int64_t m[2] = {0, 0};
+    int64_t *off[2] = {nullptr, nullptr}, *mid[2] = {nullptr, nullptr};
+    int32_t *adj[2] = {nullptr, nullptr};
+    int32_t *perm = nullptr;
+    uint8_t *label = nullptr;
+    GraphView gv{};
+    // search buffers
+    int64_t cap_rows = 0, cap_emit = 0;
+    int32_t *F[GPM_MAXP] = {};
+    int64_t *beg[GPM_MAXP] = {}, *cnt[GPM_MAXP] = {}, *pref[GPM_MAXP] = {};
+    void *scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    int32_t *emit = nullptr, *emit_host = nullptr;
+    unsigned long long *ctr = nullptr;       // device counters
+    unsigned long long *ctr_host = nullptr;  // pinned mirror for read-back
+    int64_t *i64_dev = nullptr, *i64_host = nullptr;
+    std::vector<EventPair> events;
+    size_t events_used = 0;
+    // results of the last search
+    uint64_t canonical = 0, alg_bytes = 0, tail_bytes = 0, chunks = 0;
+    uint64_t rows_in[GPM_MAXP] = {};
+    double ms_tail = 0, ms_extend = 0;
+    uint64_t tail_launches = 0, extend_launches = 0;
+    int rc = 0;
+    std::string err;
+};
+
+struct RowBatch {
+    std::vector<int32_t> rows;
+    uint64_t nrows;
+};
+
+struct gpm_ctx {
+    std::vector<DevState> devs;
+    gpm_graph_info info{};
+    bool have_graph = false, have_plan = false;
+    gpm_plan plan{};
+    std::vector<int8_t> aut;
+    PlanView pv{};
+    TailInfo ti{};
+    bool use_tail = true;
+    int64_t chunk_roots = 1 << 16;
+    int64_t root_lo = 0, root_hi = 0;
+    volatile uint64_t *shared_cursor = nullptr;
+    std::atomic<uint64_t> own_cursor{0};
+    // row hand-off from device threads to the calling thread
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<RowBatch> queue;
+    int workers_live = 0;
+    std::atomic<bool> stop{false};
+    gpm_stats stats{};
+};
+
+static int64_t env_i64(const char *name, int64_t dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoll(v) : dflt;
+}
+
+extern "C" int gpm_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        fail(GPM_ENODEV, "hipGetDeviceCount failed");
+        return 0;
+    }
+    return n;
+}
+
+static void free_graph(DevState &d) {
+    (void)hipSetDevice(d.dev);
+    for (int dir = 0; dir < 2; ++dir) {
+        if (dir == 1 && d.off[1] == d.off[0]) {
+            d.off[1] = nullptr;
+            d.adj[1] = nullptr;
+            d.mid[1] = nullptr;
+        }
+        (void)hipFree(d.off[dir]);
+        (void)hipFree(d.adj[dir]);
+        (void)hipFree(d.mid[dir]);
+        d.off[dir] = nullptr;
+        d.adj[dir] = nullptr;
+        d.mid[dir] = nullptr;
+    }
+    (void)hipFree(d.perm);
+    (void)hipFree(d.label);
+    d.perm = nullptr;
+    d.label = nullptr;
+}
+
+static void free_buffers(DevState &d) {
+    (void)hipSetDevice(d.dev);
+    for (int k = 0; k < GPM_MAXP; ++k) {
+        (void)hipFree(d.F[k]);
+        (void)hipFree(d.beg[k]);
+        (void)hipFree(d.cnt[k]);
+        (void)hipFree(d.pref[k]);
+        d.F[k] = nullptr;
+        d.beg[k] = d.cnt[k] = d.pref[k] = nullptr;
+    }
+    (void)hipFree(d.scan_tmp);
+    (void)hipFree(d.emit);
+    (void)hipHostFree(d.emit_host);
+    d.scan_tmp = nullptr;
+    d.emit = nullptr;
+    d.emit_host = nullptr;
+}
+
+extern "C" void gpm_hip_destroy(gpm_ctx *ctx) {
+    if (!ctx) return;
+    for (auto &d : ctx->devs) {
+        (void)hipSetDevice(d.dev);
+        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        free_graph(d);
+        free_buffers(d);
+        for (auto &ev : d.events) {
+            (void)hipEventDestroy(ev.a);
+            (void)hipEventDestroy(ev.b);
+        }
+        (void)hipFree(d.ctr);
+        (void)hipHostFree(d.ctr_host);
+        (void)hipFree(d.i64_dev);
+        (void)hipHostFree(d.i64_host);
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+    }
+    delete ctx;
+}
+
+extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
+    if (!out || ngpus < 1 || ngpus > 8) return fail(GPM_EINVAL, "ngpus must be 1..8");
+    int have = gpm_hip_device_count();
+    if (have < 1) return fail(GPM_ENODEV, "no HIP device is visible");
+    gpm_ctx *ctx = new gpm_ctx();
+    ctx->devs.resize((size_t)ngpus);
+    for (int i = 0; i < ngpus; ++i) {
+        DevState &d = ctx->devs[(size_t)i];
+        d.dev = devices ? devices[i] : i;
+        if (d.dev < 0 || d.dev >= have) {
+            gpm_hip_destroy(ctx);
+            return fail(GPM_EINVAL, "device %d not present (%d visible)", d.dev, have);
+        }
+        hipError_t e = hipSetDevice(d.dev);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(&d.ctr, CTR_COUNT * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipHostMalloc(&d.ctr_host, CTR_COUNT * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc(&d.i64_dev, 4 * sizeof(int64_t));
+        if (e == hipSuccess) e = hipHostMalloc(&d.i64_host, 4 * sizeof(int64_t));
+        if (e != hipSuccess) {
+            gpm_hip_destroy(ctx);
+            return fail(GPM_ENODEV, "set-up of device %d failed: %s", d.dev, hipGetErrorString(e));
+        }
+    }
+    ctx->chunk_roots = env_i64("GPM_CHUNK_ROOTS", 1 << 16);
+    if (ctx->chunk_roots < 1) ctx->chunk_roots = 1;
+    ctx->use_tail = env_i64("GPM_NO_TAIL", 0) == 0;
+    *out = ctx;
+    return GPM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// graph upload: copy, validate, renumber by degree, rebuild sorted CSR
+// ---------------------------------------------------------------------------
+
+static inline unsigned grid_for(int64_t n, int block = 256) { return (unsigned)((n + block - 1) / block); }
+
+static int bits_for(int64_t n) {
+    int b = 1;
+    while (((int64_t)1 << b) < n) ++b;
+    return b;
+}
+
+// Build one direction of the renumbered CSR on the current device.
+static int rebuild_direction(DevState &d, int dir, const int64_t *old_off, const int32_t *old_adj, int64_t m,
+                             const int32_t *rank, uint32_t *flags) {
+    const int32_t n = d.n;
+    hipStream_t s = d.stream;
+    int64_t *new_deg = nullptr;
+    HIP_TRY(hipMalloc(&d.off[dir], ((size_t)n + 1) * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&d.mid[dir], ((size_t)n + 1) * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&d.adj[dir], ((size_t)m + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&new_deg, ((size_t)n + 1) * sizeof(int64_t)));
+    int32_t *rank_tmp = nullptr;  // k_scatter_rank writes rank again; harmless, keeps one kernel
+    HIP_TRY(hipMalloc(&rank_tmp, ((size_t)n + 1) * sizeof(int32_t)));
+    if (n > 0) k_scatter_rank<<<grid_for(n), 256, 0, s>>>(n, d.perm, rank_tmp, old_off, new_deg);
+    HIP_TRY(hipMemsetAsync(d.off[dir], 0, sizeof(int64_t), s));
+    size_t tmp_bytes = 0;
+    void *tmp = nullptr;
+    if (n > 0) {
+        HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, new_deg, d.off[dir] + 1, (size_t)n,
+                                        rocprim::plus<int64_t>(), s));
+        HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+        HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, new_deg, d.off[dir] + 1, (size_t)n, rocprim::plus<int64_t>(),
+                                        s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipFree(tmp));
+    }
+    if (m > 0) {
+        uint64_t *keys = nullptr, *keys2 = nullptr;
+        HIP_TRY(hipMalloc(&keys, (size_t)m * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&keys2, (size_t)m * sizeof(uint64_t)));
+        k_arc_keys<<<grid_for(m), 256, 0, s>>>(n, m, old_off, old_adj, rank, keys);
+        unsigned end_bit = 32u + (unsigned)bits_for(n);
+        tmp_bytes = 0;
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, keys2, (size_t)m, 0u, end_bit, s));
+        HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+        HIP_TRY(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, keys2, (size_t)m, 0u, end_bit, s));
+        k_keys_to_adj<<<grid_for(m), 256, 0, s>>>(m, keys2, d.adj[dir]);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipFree(tmp));
+        HIP_TRY(hipFree(keys));
+        HIP_TRY(hipFree(keys2));
+    }
+    if (n > 0) k_mid_and_flags<<<grid_for(n), 256, 0, s>>>(n, d.off[dir], d.adj[dir], d.mid[dir], flags);
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipFree(new_deg));
+    HIP_TRY(hipFree(rank_tmp));
+    d.m[dir] = m;
+    return GPM_OK;
+}
+
+static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int32_t *out_adj, const int64_t *in_off,
+                      const int32_t *in_adj, const uint8_t *labels, uint32_t *flags_out) {
+    HIP_TRY(hipSetDevice(d.dev));
+    free_graph(d);
+    hipStream_t s = d.stream;
+    d.n = n;
+    const int64_t m_out = out_off[n];
+    const int64_t m_in = in_off ? in_off[n] : 0;
+    int64_t *o_off[2] = {nullptr, nullptr};
+    int32_t *o_adj[2] = {nullptr, nullptr};
+    uint32_t *flags = nullptr;
+    HIP_TRY(hipMalloc(&flags, sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(flags, 0, sizeof(uint32_t), s));
+    const int ndir = in_off ? 2 : 1;
+    for (int dir = 0; dir < ndir; ++dir) {
+        const int64_t *ho = dir ? in_off : out_off;
+        const int32_t *ha = dir ? in_adj : out_adj;
+        int64_t m = dir ? m_in : m_out;
+        HIP_TRY(hipMalloc(&o_off[dir], ((size_t)n + 1) * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(&o_adj[dir], ((size_t)m + 1) * sizeof(int32_t)));
+        HIP_TRY(hipMemcpyAsync(o_off[dir], ho, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        if (m > 0) HIP_TRY(hipMemcpyAsync(o_adj[dir], ha, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        k_validate_off<<<grid_for((int64_t)n + 1), 256, 0, s>>>(n, m, o_off[dir], flags);
+        if (m > 0) k_validate_adj<<<grid_for(m), 256, 0, s>>>(n, m, o_adj[dir], flags);
+    }
+    uint32_t hflags = 0;
+    HIP_TRY(hipMemcpyAsync(&hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (hflags & 2u) {
+        for (int dir = 0; dir < 2; ++dir) {
+            (void)hipFree(o_off[dir]);
+            (void)hipFree(o_adj[dir]);
+        }
+        (void)hipFree(flags);
+        return fail(GPM_EINVAL, "CSR arrays are inconsistent (offsets not monotone or ids out of range)");
+    }
+
+    // renumber by ascending total degree, ties by id (stable radix sort)
+    uint32_t *deg = nullptr, *deg2 = nullptr;
+    int32_t *ids = nullptr, *rank = nullptr;
+    HIP_TRY(hipMalloc(&deg, ((size_t)n + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&deg2, ((size_t)n + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&ids, ((size_t)n + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&rank, ((size_t)n + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&d.perm, ((size_t)n + 1) * sizeof(int32_t)));
+    if (n > 0) {
+        k_total_degree<<<grid_for(n), 256, 0, s>>>(n, o_off[0], o_off[1], deg, ids);
+        size_t tmp_bytes = 0;
+        void *tmp = nullptr;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, deg, deg2, ids, d.perm, (size_t)n, 0u, 32u, s));
+        HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, deg, deg2, ids, d.perm, (size_t)n, 0u, 32u, s));
+        int64_t *scratch_deg = nullptr;
+        HIP_TRY(hipMalloc(&scratch_deg, ((size_t)n + 1) * sizeof(int64_t)));
+        k_scatter_rank<<<grid_for(n), 256, 0, s>>>(n, d.perm, rank, o_off[0], scratch_deg);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipFree(tmp));
+        HIP_TRY(hipFree(scratch_deg));
+    }
+    int rc = rebuild_direction(d, 0, o_off[0], o_adj[0], m_out, rank, flags);
+    if (rc == GPM_OK && in_off) rc = rebuild_direction(d, 1, o_off[1], o_adj[1], m_in, rank, flags);
+    if (rc != GPM_OK) return rc;
+    if (!in_off) {
+        d.off[1] = d.off[0];
+        d.adj[1] = d.adj[0];
+        d.mid[1] = d.mid[0];
+        d.m[1] = d.m[0];
+    }
+    if (labels) {
+        uint8_t *raw = nullptr;
+        HIP_TRY(hipMalloc(&raw, (size_t)n + 1));
+        HIP_TRY(hipMalloc(&d.label, (size_t)n + 1));
+        HIP_TRY(hipMemcpyAsync(raw, labels, (size_t)n, hipMemcpyHostToDevice, s));
+        if (n > 0) k_permute_labels<<<grid_for(n), 256, 0, s>>>(n, d.perm, raw, d.label);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipFree(raw));
+    }
+    HIP_TRY(hipMemcpyAsync(&hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *flags_out = hflags;
+    for (int dir = 0; dir < 2; ++dir) {
+        HIP_TRY(hipFree(o_off[dir]));
+        HIP_TRY(hipFree(o_adj[dir]));
+    }
+    HIP_TRY(hipFree(deg));
+    HIP_TRY(hipFree(deg2));
+    HIP_TRY(hipFree(ids));
+    HIP_TRY(hipFree(rank));
+    HIP_TRY(hipFree(flags));
+    d.gv.n = n;
+    for (int dir = 0; dir < 2; ++dir) {
+        d.gv.off[dir] = d.off[dir];
+        d.gv.adj[dir] = d.adj[dir];
+        d.gv.mid[dir] = d.mid[dir];
+    }
+    d.gv.label = d.label;
+    return GPM_OK;
+}
+
+extern "C" int gpm_hip_upload_graph(gpm_ctx *ctx, int32_t n, const int64_t *out_off, const int32_t *out_adj,
+                                    const int64_t *in_off, const int32_t *in_adj, const uint8_t *labels) {
+    if (!ctx || n < 0 || !out_off || (!out_adj && out_off[n] > 0)) return fail(GPM_EINVAL, "bad graph arguments");
+    if ((in_off == nullptr) != (in_adj == nullptr) && in_off && in_off[n] > 0)
+        return fail(GPM_EINVAL, "in_off and in_adj must be given together");
+    if (out_off[0] != 0 || out_off[n] < 0 || (in_off && in_off[n] != out_off[n]))
+        return fail(GPM_EINVAL, "arc counts of the two directions differ");
+    ctx->have_graph = false;
+    ctx->have_plan = false;
+    uint32_t flags = 0;
+    for (auto &d : ctx->devs) {
+        int rc = upload_one(d, n, out_off, out_adj, in_off, in_adj, labels, &flags);
+        if (rc != GPM_OK) return rc;
+    }
+    int64_t max_out = 0, max_in = 0;
+    for (int32_t v = 0; v < n; ++v) {
+        max_out = std::max(max_out, out_off[v + 1] - out_off[v]);
+        if (in_off) max_in = std::max(max_in, in_off[v + 1] - in_off[v]);
+    }
+    ctx->info.n = n;
+    ctx->info.m_out = out_off[n];
+    ctx->info.symmetric = in_off == nullptr;
+    ctx->info.simple = (flags & 1u) == 0;
+    ctx->info.max_out_deg = (int32_t)max_out;
+    ctx->info.max_in_deg = (int32_t)(in_off ? max_in : max_out);
+    ctx->info.has_labels = labels != nullptr;
+    ctx->root_lo = 0;
+    ctx->root_hi = n;
+    ctx->have_graph = true;
+    return GPM_OK;
+}
+
+extern "C" int gpm_hip_graph_info(const gpm_ctx *ctx, gpm_graph_info *info) {
+    if (!ctx || !info) return fail(GPM_EINVAL, "null argument");
+    if (!ctx->have_graph) return fail(GPM_ESTATE, "no graph uploaded");
+    *info = ctx->info;
+    return GPM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+
+static bool same_list_set(const std::vector<std::pair<int, int>> &a, const std::vector<std::pair<int, int>> &b) {
+    if (a.size() != b.size()) return false;
+    for (auto &x : a) {
+        bool found = false;
+        for (auto &y : b) found |= x == y;
+        if (!found) return false;
+    }
+    return true;
+}
+
+extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
+    if (!ctx || !p) return fail(GPM_EINVAL, "null argument");
+    if (!ctx->have_graph) return fail(GPM_ESTATE, "upload the graph before the plan");
+    const int P = p->n_levels;
+    if (P < 1 || P > GPM_MAX_PATTERN) return fail(GPM_EINVAL, "n_levels must be 1..%d", GPM_MAX_PATTERN);
+    bool seen[GPM_MAXP] = {};
+    bool any_bound = false;
+    for (int k = 0; k < P; ++k) {
+        if (p->order[k] < 0 || p->order[k] >= P || seen[p->order[k]])
+            return fail(GPM_EINVAL, "order is not a permutation of the pattern vertices");
+        seen[p->order[k]] = true;
+        if (p->label[k] > 255) return fail(GPM_EINVAL, "labels must fit 8 bits");
+        if (p->label[k] >= 0 && !ctx->info.has_labels)
+            return fail(GPM_EINVAL, "plan has labels but the graph has none");
+        if (k == 0) continue;
+        if (p->src_level[k] < 0 || p->src_level[k] >= k || (p->src_dir[k] | 1) != 1)
+            return fail(GPM_EINVAL, "level %d: bad source", k);
+        if (p->n_cons[k] < 0 || p->n_cons[k] > GPM_MAX_CONS || p->n_lower[k] < 0 || p->n_lower[k] > GPM_MAX_CONS ||
+            p->n_upper[k] < 0 || p->n_upper[k] > GPM_MAX_CONS)
+            return fail(GPM_EINVAL, "level %d: bad list sizes", k);
+        for (int j = 0; j < p->n_cons[k]; ++j)
+            if (p->cons_level[k][j] < 0 || p->cons_level[k][j] >= k || (p->cons_dir[k][j] | 1) != 1)
+                return fail(GPM_EINVAL, "level %d: bad constraint %d", k, j);
+        for (int j = 0; j < p->n_lower[k]; ++j)
+            if (p->lower_level[k][j] < 0 || p->lower_level[k][j] >= k)
+                return fail(GPM_EINVAL, "level %d: bad lower bound %d", k, j);
+        for (int j = 0; j < p->n_upper[k]; ++j)
+            if (p->upper_level[k][j] < 0 || p->upper_level[k][j] >= k)
+                return fail(GPM_EINVAL, "level %d: bad upper bound %d", k, j);
+        any_bound |= p->n_lower[k] > 0 || p->n_upper[k] > 0;
+    }
+    if (p->n_aut < 1 || (p->n_aut > 1 && !p->aut)) return fail(GPM_EINVAL, "bad automorphism table");
+    if ((any_bound || p->n_aut > 1) && !ctx->info.simple)
+        return fail(GPM_EINVAL, "ordering bounds need a data graph without duplicate arcs and self loops");
+
+    ctx->plan = *p;
+    ctx->aut.assign(p->aut ? p->aut : nullptr, p->aut ? p->aut + p->n_aut * (uint64_t)P : nullptr);
+    ctx->plan.aut = ctx->aut.empty() ? nullptr : ctx->aut.data();
+
+    // order relation between levels implied by the bounds (transitive closure)
+    bool lt[GPM_MAXP][GPM_MAXP] = {};  // lt[a][b]: m[a] < m[b]
+    for (int k = 1; k < P; ++k) {
+        for (int j = 0; j < p->n_lower[k]; ++j) lt[p->lower_level[k][j]][k] = true;
+        for (int j = 0; j < p->n_upper[k]; ++j) lt[k][p->upper_level[k][j]] = true;
+    }
+    for (int mIdx = 0; mIdx < P; ++mIdx)
+        for (int a = 0; a < P; ++a)
+            for (int b = 0; b < P; ++b) lt[a][b] = lt[a][b] || (lt[a][mIdx] && lt[mIdx][b]);
+    auto part_of = [&](int owner, int k) { return lt[owner][k] ? PART_ABOVE : (lt[k][owner] ? PART_BELOW : PART_FULL); };
+
+    PlanView &pv = ctx->pv;
+    memset(&pv, 0, sizeof pv);
+    pv.P = P;
+    for (int k = 0; k < P; ++k) {
+        pv.order[k] = (int8_t)p->order[k];
+        LevelPlan &lv = pv.lv[k];
+        lv.label = p->label[k];
+        lv.min_out = ctx->info.simple ? p->min_out_deg[k] : 0;
+        lv.min_in = ctx->info.simple ? p->min_in_deg[k] : 0;
+        if (k == 0) continue;
+        lv.src_level = (int8_t)p->src_level[k];
+        lv.src_dir = (int8_t)(ctx->info.symmetric ? 0 : p->src_dir[k]);
+        lv.src_part = (int8_t)part_of(lv.src_level, k);
+        lv.n_cons = (int8_t)p->n_cons[k];
+        lv.n_lower = (int8_t)p->n_lower[k];
+        lv.n_upper = (int8_t)p->n_upper[k];
+        for (int j = 0; j < lv.n_cons; ++j) {
+            lv.cons_level[j] = (int8_t)p->cons_level[k][j];
+            lv.cons_dir[j] = (int8_t)(ctx->info.symmetric ? 0 : p->cons_dir[k][j]);
+            lv.cons_part[j] = (int8_t)part_of(lv.cons_level[j], k);
+        }
+        for (int j = 0; j < lv.n_lower; ++j) lv.lower_level[j] = (int8_t)p->lower_level[k][j];
+        for (int j = 0; j < lv.n_upper; ++j) lv.upper_level[j] = (int8_t)p->upper_level[k][j];
+        lv.lower_is_src = lv.n_lower == 1 && lv.lower_level[0] == lv.src_level;
+    }
+
+    // relation between the last two levels (fused intersection kernel)
+    TailInfo &ti = ctx->ti;
+    memset(&ti, 0, sizeof ti);
+    ti.any_shortest = ctx->info.simple;
+    if (P >= 3) {
+        const int L = P - 2;
+        const LevelPlan &A = pv.lv[L], &B = pv.lv[L + 1];
+        std::vector<std::pair<int, int>> la, lb_rest;
+        la.push_back({A.src_level, A.src_dir});
+        for (int j = 0; j < A.n_cons; ++j) la.push_back({A.cons_level[j], A.cons_dir[j]});
+        int n_extra = 0;
+        auto addB = [&](int lvl, int dir) {
+            if (lvl == L) {
+                if (n_extra < 2) {
+                    ti.extra_dir[n_extra] = (int8_t)dir;
+                    ti.extra_part[n_extra] = (int8_t)part_of(L, L + 1);
+                }
+                n_extra++;
+            } else {
+                lb_rest.push_back({lvl, dir});
+            }
+        };
+        addB(B.src_level, B.src_dir);
+        for (int j = 0; j < B.n_cons; ++j) addB(B.cons_level[j], B.cons_dir[j]);
+        bool same_bounds = true;
+        for (int t = 0; t < L; ++t) same_bounds &= lt[t][L] == lt[t][L + 1] && lt[L][t] == lt[L + 1][t];
+        bool same_filters = A.label == B.label && A.min_out == B.min_out && A.min_in == B.min_in;
+        ti.n_extra = (int8_t)std::min(n_extra, 2);
+        ti.b_lower_is_a = lt[L][L + 1];
+        ti.b_upper_is_a = lt[L + 1][L];
+        ti.reuse = ctx->info.simple && n_extra >= 1 && n_extra <= 2 && same_list_set(la, lb_rest) && same_bounds &&
+                   same_filters && env_i64("GPM_NO_REUSE", 0) == 0;
+    }
+    ctx->have_plan = true;
+    return GPM_OK;
+}
+
+extern "C" int gpm_hip_set_cursor(gpm_ctx *ctx, volatile uint64_t *cursor) {
+    if (!ctx) return fail(GPM_EINVAL, "null context");
+    ctx->shared_cursor = cursor;
+    return GPM_OK;
+}
+
+extern "C" int gpm_hip_set_roots(gpm_ctx *ctx, int64_t lo, int64_t hi) {
+    if (!ctx) return fail(GPM_EINVAL, "null context");
+    if (!ctx->have_graph) return fail(GPM_ESTATE, "no graph uploaded");
+    if (lo < 0 || hi < lo || hi > ctx->info.n) return fail(GPM_EINVAL, "root range out of bounds");
+    ctx->root_lo = lo;
+    ctx->root_hi = hi;
+    return GPM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// search driver
+// ---------------------------------------------------------------------------
+
+struct SearchArgs {
+    gpm_ctx *ctx;
+    bool count_only;
+    bool direct_sink;  // single GPU: rows go straight to the sink on this thread
+    gpm_row_sink sink;
+    void *user;
+};
+
+static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
+    HIP_TRY(hipSetDevice(d.dev));
+    const int P = ctx->pv.P;
+    int64_t want_rows = env_i64("GPM_ARENA_ROWS", (int64_t)1 << 24);
+    int64_t min_rows = std::max<int64_t>((int64_t)std::max(ctx->info.max_out_deg, ctx->info.max_in_deg) + 64,
+                                         ctx->chunk_roots);
+    want_rows = std::max(want_rows, min_rows);
+    int64_t want_emit = count_only ? 0 : std::max(env_i64("GPM_EMIT_ROWS", (int64_t)1 << 22), min_rows);
+    if (d.cap_rows != want_rows) {
+        free_buffers(d);
+        d.cap_rows = want_rows;
+        d.cap_emit = 0;
+    }
+    // frontiers F[k] hold rows of k+1 ids; levels 0..P-2 can be materialised
+    for (int k = 0; k + 1 < std::max(P, 2); ++k) {
+        if (!d.F[k]) HIP_TRY(hipMalloc(&d.F[k], (size_t)d.cap_rows * (size_t)(k + 1) * sizeof(int32_t)));
+        if (!d.beg[k]) HIP_TRY(hipMalloc(&d.beg[k], (size_t)d.cap_rows * sizeof(int64_t)));
+        if (!d.cnt[k]) HIP_TRY(hipMalloc(&d.cnt[k], (size_t)d.cap_rows * sizeof(int64_t)));
+        if (!d.pref[k]) {
+            HIP_TRY(hipMalloc(&d.pref[k], ((size_t)d.cap_rows + 1) * sizeof(int64_t)));
+            HIP_TRY(hipMemsetAsync(d.pref[k], 0, sizeof(int64_t), d.stream));
+        }
+    }
+    if (!d.scan_tmp) {
+        size_t bytes = 0;
+        HIP_TRY(rocprim::inclusive_scan(nullptr, bytes, d.cnt[0], d.pref[0] + 1, (size_t)d.cap_rows,
+                                        rocprim::plus<int64_t>(), d.stream));
+        d.scan_tmp_bytes = bytes ? bytes : 8;
+        HIP_TRY(hipMalloc(&d.scan_tmp, d.scan_tmp_bytes));
+    }
+    if (want_emit > d.cap_emit) {
+        (void)hipFree(d.emit);
+        (void)hipHostFree(d.emit_host);
+        d.emit = nullptr;
+        d.emit_host = nullptr;
+        HIP_TRY(hipMalloc(&d.emit, (size_t)want_emit * (size_t)P * sizeof(int32_t)));
+        HIP_TRY(hipHostMalloc(&d.emit_host, (size_t)want_emit * (size_t)P * sizeof(int32_t)));
+        d.cap_emit = want_emit;
+    }
+    return GPM_OK;
+}
+
+static int read_ctr(DevState &d, int slot, uint64_t *out) {
+    HIP_TRY(hipMemcpyAsync(d.ctr_host + slot, d.ctr + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           d.stream));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    *out = d.ctr_host[slot];
+    return GPM_OK;
+}
+
+static int timed_begin(DevState &d, int kind) {
+    if (d.events_used == d.events.size()) {
+        EventPair ev{};
+        ev.kind = kind;
+        HIP_TRY(hipEventCreate(&ev.a));
+        HIP_TRY(hipEventCreate(&ev.b));
+        d.events.push_back(ev);
+    }
+    d.events[d.events_used].kind = kind;
+    HIP_TRY(hipEventRecord(d.events[d.events_used].a, d.stream));
+    return GPM_OK;
+}
+
+static int timed_end(DevState &d) {
+    HIP_TRY(hipEventRecord(d.events[d.events_used].b, d.stream));
+    d.events_used++;
+    return GPM_OK;
+}
+
+// Turn timing events into milliseconds; the stream must be idle.
+static int collect_times(DevState &d) {
+    for (size_t i = 0; i < d.events_used; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, d.events[i].a, d.events[i].b));
+        if (d.events[i].kind == 0) {
+            d.ms_tail += ms;
+            d.tail_launches++;
+        } else {
+            d.ms_extend += ms;
+            d.extend_launches++;
+        }
+    }
+    d.events_used = 0;
+    return GPM_OK;
+}
+
+// Hand finished rows (pattern-vertex order, 1-based ids) to the sink, after
+// expanding each into its automorphic images.
+static int deliver(const SearchArgs &a, DevState &d, const int32_t *rows, uint64_t nrows) {
+    gpm_ctx *ctx = a.ctx;
+    const int P = ctx->pv.P;
+    const uint64_t n_aut = ctx->plan.n_aut;
+    const int8_t *aut = ctx->plan.aut;
+    (void)d;
+    if (nrows == 0) return GPM_OK;
+    const uint64_t step = std::max<uint64_t>(1, ((uint64_t)1 << 20) / n_aut);
+    for (uint64_t r0 = 0; r0 < nrows; r0 += step) {
+        uint64_t r1 = std::min(nrows, r0 + step);
+        RowBatch batch;
+        batch.nrows = (r1 - r0) * n_aut;
+        batch.rows.resize((size_t)batch.nrows * (size_t)P);
+        int32_t *o = batch.rows.data();
+        for (uint64_t r = r0; r < r1; ++r) {
+            const int32_t *m = rows + r * (uint64_t)P;
+            if (n_aut == 1) {
+                memcpy(o, m, (size_t)P * sizeof(int32_t));
+                o += P;
+                continue;
+            }
+            for (uint64_t i = 0; i < n_aut; ++i, o += P)
+                for (int v = 0; v < P; ++v) o[v] = m[aut[i * (uint64_t)P + (uint64_t)v]];
+        }
+        if (a.direct_sink) {
+            if (a.sink && a.sink(a.user, batch.rows.data(), batch.nrows, P) != 0) {
+                ctx->stop = true;
+                return fail(GPM_ESINK, "the row sink stopped the search");
+            }
+        } else {
+            std::unique_lock<std::mutex> lk(ctx->mu);
+            ctx->cv.wait(lk, [&] { return ctx->queue.size() < 8 || ctx->stop; });
+            if (ctx->stop) return fail(GPM_ESINK, "the row sink stopped the search");
+            ctx->queue.push_back(std::move(batch));
+            ctx->cv.notify_all();
+        }
+    }
+    return GPM_OK;
+}
+
+// Expand the partial matches F[k-1][0..nrows) (k ids each) to completion.
+static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
+    gpm_ctx *ctx = a.ctx;
+    const int P = ctx->pv.P;
+    hipStream_t s = d.stream;
+    if (nrows == 0 || ctx->stop) return GPM_OK;
+    d.rows_in[k - 1] += (uint64_t)nrows;
+    const int32_t *rows = d.F[k - 1];
+
+    if (a.count_only && ctx->use_tail && k == P - 2) {
+        unsigned blocks = (unsigned)std::min<int64_t>((nrows + TAIL_WAVES - 1) / TAIL_WAVES, 16384);
+        int rc = timed_begin(d, 0);
+        if (rc) return rc;
+        k_tail<<<blocks, TAIL_WAVES * GPM_WAVE, 0, s>>>(d.gv, ctx->pv, ctx->ti, rows, nrows, d.ctr + CTR_TAIL_MATCHES,
+                                                        d.ctr + CTR_TAIL_BYTES);
+        HIP_TRY(hipGetLastError());
+        d.rows_in[k] += 0;  // rows of the fused level never materialise
+        return timed_end(d);
+    }
+
+    // candidate ranges and their prefix sums
+    k_ranges<<<grid_for(nrows), 256, 0, s>>>(d.gv, ctx->pv, k, rows, nrows, d.beg[k - 1], d.cnt[k - 1],
+                                             d.ctr + CTR_BYTES);
+    HIP_TRY(hipGetLastError());
+    size_t tmp_bytes = d.scan_tmp_bytes;
+    HIP_TRY(rocprim::inclusive_scan(d.scan_tmp, tmp_bytes, d.cnt[k - 1], d.pref[k - 1] + 1, (size_t)nrows,
+                                    rocprim::plus<int64_t>(), s));
+    HIP_TRY(hipMemcpyAsync(d.i64_host, d.pref[k - 1] + nrows, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int64_t total = d.i64_host[0];
+    if (total == 0) return GPM_OK;
+
+    const bool terminal = k == P - 1;
+    const int64_t cap = terminal ? (a.count_only ? ((int64_t)1 << 30) : d.cap_emit) : d.cap_rows;
+    int64_t b0 = 0, g0 = 0;
+    while (b0 < nrows && !ctx->stop) {
+        int64_t b1 = nrows, gcount = total - g0;
+        if (gcount > cap) {
+            k_batch_end<<<1, 1, 0, s>>>(d.pref[k - 1], nrows, b0, cap, d.i64_dev);
+            HIP_TRY(hipMemcpyAsync(d.i64_host, d.i64_dev, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            b1 = d.i64_host[0];
+            gcount = d.i64_host[1];
+            if (gcount > cap) return fail(GPM_ERUNTIME, "one candidate list exceeds the frontier arena");
+        }
+        if (gcount > 0) {
+            const int64_t g1 = g0 + gcount;
+            int rc = timed_begin(d, 1);
+            if (rc) return rc;
+            if (terminal && a.count_only) {
+                k_extend<MODE_COUNT><<<grid_for(gcount), 256, 0, s>>>(d.gv, ctx->pv, k, rows, d.pref[k - 1],
+                                                                      d.beg[k - 1], b0, b1, g0, g1, nullptr,
+                                                                      d.ctr + CTR_MATCHES, nullptr);
+                HIP_TRY(hipGetLastError());
+                rc = timed_end(d);
+                if (rc) return rc;
+            } else if (terminal) {
+                HIP_TRY(hipMemsetAsync(d.ctr + CTR_EMIT, 0, sizeof(unsigned long long), s));
+                k_extend<MODE_EMIT><<<grid_for(gcount), 256, 0, s>>>(d.gv, ctx->pv, k, rows, d.pref[k - 1],
+                                                                     d.beg[k - 1], b0, b1, g0, g1, d.emit,
+                                                                     d.ctr + CTR_EMIT, d.perm);
+                HIP_TRY(hipGetLastError());
+                rc = timed_end(d);
+                if (rc) return rc;
+                uint64_t n_emit = 0;
+                rc = read_ctr(d, CTR_EMIT, &n_emit);
+                if (rc) return rc;
+                if (n_emit) {
+                    HIP_TRY(hipMemcpyAsync(d.emit_host, d.emit, (size_t)n_emit * (size_t)P * sizeof(int32_t),
+                                           hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    d.canonical += n_emit;
+                    rc = deliver(a, d, d.emit_host, n_emit);
+                    if (rc) return rc;
+                }
+            } else {
+                HIP_TRY(hipMemsetAsync(d.ctr + CTR_LEVEL0 + k, 0, sizeof(unsigned long long), s));
+                k_extend<MODE_EXTEND><<<grid_for(gcount), 256, 0, s>>>(d.gv, ctx->pv, k, rows, d.pref[k - 1],
+                                                                       d.beg[k - 1], b0, b1, g0, g1, d.F[k],
+                                                                       d.ctr + CTR_LEVEL0 + k, nullptr);
+                HIP_TRY(hipGetLastError());
+                rc = timed_end(d);
+                if (rc) return rc;
+                uint64_t n_next = 0;
+                rc = read_ctr(d, CTR_LEVEL0 + k, &n_next);
+                if (rc) return rc;
+                rc = expand(a, d, k + 1, (int64_t)n_next);
+                if (rc) return rc;
+            }
+            g0 = g1;
+        }
+        b0 = b1;
+    }
+    return GPM_OK;
+}
+
+static uint64_t claim_chunk(gpm_ctx *ctx) {
+    if (ctx->shared_cursor) return __atomic_fetch_add((uint64_t *)ctx->shared_cursor, 1, __ATOMIC_RELAXED);
+    return ctx->own_cursor.fetch_add(1, std::memory_order_relaxed);
+}
+
+static int device_search(const SearchArgs &a, DevState &d) {
+    gpm_ctx *ctx = a.ctx;
+    const int P = ctx->pv.P;
+    HIP_TRY(hipSetDevice(d.dev));
+    int rc = ensure_buffers(ctx, d, a.count_only);
+    if (rc) return rc;
+    hipStream_t s = d.stream;
+    HIP_TRY(hipMemsetAsync(d.ctr, 0, CTR_COUNT * sizeof(unsigned long long), s));
+    d.canonical = d.alg_bytes = d.tail_bytes = d.chunks = 0;
+    d.ms_tail = d.ms_extend = 0;
+    d.tail_launches = d.extend_launches = 0;
+    d.events_used = 0;
+    memset(d.rows_in, 0, sizeof d.rows_in);
+    uint64_t p1_rows = 0;
+    while (!ctx->stop) {
+        const uint64_t c = claim_chunk(ctx);
+        const int64_t lo = ctx->root_lo + (int64_t)c * ctx->chunk_roots;
+        if (lo >= ctx->root_hi || (int64_t)c < 0) break;
+        const int64_t hi = std::min(ctx->root_hi, lo + ctx->chunk_roots);
+        d.chunks++;
+        HIP_TRY(hipMemsetAsync(d.ctr + CTR_LEVEL0, 0, sizeof(unsigned long long), s));
+        k_filter_roots<<<grid_for(hi - lo), 256, 0, s>>>(d.gv, ctx->pv.lv[0], lo, hi, d.F[0], d.ctr + CTR_LEVEL0);
+        HIP_TRY(hipGetLastError());
+        uint64_t n0 = 0;
+        rc = read_ctr(d, CTR_LEVEL0, &n0);
+        if (rc) return rc;
+        if (P == 1) {
+            p1_rows += n0;
+            d.rows_in[0] += n0;
+            if (!a.count_only && n0) {
+                for (uint64_t r0 = 0; r0 < n0; r0 += (uint64_t)d.cap_emit) {
+                    uint64_t cnt = std::min<uint64_t>((uint64_t)d.cap_emit, n0 - r0);
+                    k_emit_roots<<<grid_for((int64_t)cnt), 256, 0, s>>>((int64_t)cnt, d.F[0] + r0, d.perm, d.emit);
+                    HIP_TRY(hipMemcpyAsync(d.emit_host, d.emit, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                           s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    rc = deliver(a, d, d.emit_host, cnt);
+                    if (rc) return rc;
+                }
+            }
+            continue;
+        }
+        rc = expand(a, d, 1, (int64_t)n0);
+        if (rc) return rc;
+        if (d.events_used > 4096) {
+            HIP_TRY(hipStreamSynchronize(s));
+            rc = collect_times(d);
+            if (rc) return rc;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(d.ctr_host, d.ctr, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    rc = collect_times(d);
+    if (rc) return rc;
+    if (a.count_only) d.canonical = d.ctr_host[CTR_MATCHES] + d.ctr_host[CTR_TAIL_MATCHES] + p1_rows;
+    else if (P == 1) d.canonical = p1_rows;
+    d.tail_bytes = d.ctr_host[CTR_TAIL_BYTES];
+    d.alg_bytes = d.ctr_host[CTR_BYTES] + d.tail_bytes + 4ull * d.rows_in[0];
+    return GPM_OK;
+}
+
+extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, void *user, uint64_t *total) {
+    if (!ctx) return fail(GPM_EINVAL, "null context");
+    if (!ctx->have_graph || !ctx->have_plan) return fail(GPM_ESTATE, "upload a graph and set a plan first");
+    if (!count_only && !sink) return fail(GPM_EINVAL, "output mode needs a row sink");
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    ctx->stop = false;
+    ctx->own_cursor = 0;
+    SearchArgs a{ctx, count_only != 0, ctx->devs.size() == 1, sink, user};
+    int rc = GPM_OK;
+    if (ctx->devs.size() == 1) {
+        rc = device_search(a, ctx->devs[0]);
+    } else {
+        std::vector<std::thread> threads;
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            ctx->workers_live = (int)ctx->devs.size();
+            ctx->queue.clear();
+        }
+        for (auto &d : ctx->devs) {
+            threads.emplace_back([&a, &d, ctx] {
+                d.rc = device_search(a, d);
+                if (d.rc) {
+                    d.err = gpm_hip_last_error();
+                    ctx->stop = true;
+                }
+                std::lock_guard<std::mutex> lk(ctx->mu);
+                ctx->workers_live--;
+                ctx->cv.notify_all();
+            });
+        }
+        for (;;) {  // the calling thread is the only one that runs the sink
+            RowBatch batch;
+            {
+                std::unique_lock<std::mutex> lk(ctx->mu);
+                ctx->cv.wait(lk, [&] { return !ctx->queue.empty() || ctx->workers_live == 0; });
+                if (ctx->queue.empty()) break;
+                batch = std::move(ctx->queue.front());
+                ctx->queue.pop_front();
+                ctx->cv.notify_all();
+            }
+            if (sink && !ctx->stop && sink(user, batch.rows.data(), batch.nrows, ctx->pv.P) != 0) {
+                ctx->stop = true;
+                rc = fail(GPM_ESINK, "the row sink stopped the search");
+                ctx->cv.notify_all();
+            }
+        }
+        for (auto &t : threads) t.join();
+        for (auto &d : ctx->devs)
+            if (d.rc && rc == GPM_OK) rc = fail(d.rc, "%s", d.err.c_str());
+    }
+    gpm_stats &st = ctx->stats;
+    memset(&st, 0, sizeof st);
+    for (size_t i = 0; i < ctx->devs.size(); ++i) {
+        DevState &d = ctx->devs[i];
+        st.canonical += d.canonical;
+        st.alg_bytes += d.alg_bytes;
+        st.tail_alg_bytes += d.tail_bytes;
+        st.ms_tail_kernel += d.ms_tail;
+        st.ms_extend_kernel += d.ms_extend;
+        st.tail_launches += d.tail_launches;
+        st.extend_launches += d.extend_launches;
+        for (int k = 0; k < GPM_MAXP; ++k) st.rows_in[k] += d.rows_in[k];
+        st.chunks[i] = d.chunks;
+    }
+    st.matches = st.canonical * ctx->plan.n_aut;
+    st.ms_total =
+        1e3 * (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
+    if (total) *total = st.matches;
+    return rc;
+}
+
+extern "C" int gpm_hip_stats(const gpm_ctx *ctx, gpm_stats *stats) {
+    if (!ctx || !stats) return fail(GPM_EINVAL, "null argument");
+    *stats = ctx->stats;
+    return GPM_OK;
+}

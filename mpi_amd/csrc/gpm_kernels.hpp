@@ -1,0 +1,357 @@
+// Hand-written gfx950 kernels of the match search.
+//
+// Arithmetic is 32-bit id compares and 64-bit counts; the work is irregular
+// integer set intersection, bounded by memory traffic, so there is no MFMA
+// anywhere.  Wave width is 64 throughout.
+#pragma once
+#include "gpm_device.hpp"
+
+// ---------------------------------------------------------------------------
+// Graph preparation (runs once per upload)
+// ---------------------------------------------------------------------------
+
+// Total degree of every vertex (sort key of the renumbering).
+__global__ void k_total_degree(int32_t n, const int64_t *out_off, const int64_t *in_off, uint32_t *deg, int32_t *ids) {
+    int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    int64_t d = out_off[v + 1] - out_off[v];
+    if (in_off) d += in_off[v + 1] - in_off[v];
+    else d *= 2;
+    deg[v] = (uint32_t)min(d, (int64_t)0xffffffffll);
+    ids[v] = v;
+}
+
+// rank[old] = new from perm[new] = old, and the new degree array.
+__global__ void k_scatter_rank(int32_t n, const int32_t *perm, int32_t *rank, const int64_t *old_off, int64_t *new_deg) {
+    int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    int32_t o = perm[v];
+    rank[o] = v;
+    new_deg[v] = old_off[o + 1] - old_off[o];
+}
+
+// One 64-bit sort key per arc: (new source id << 32) | new target id.
+__global__ void k_arc_keys(int32_t n, int64_t m, const int64_t *off, const int32_t *adj, const int32_t *rank,
+                           uint64_t *keys) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    int32_t lo = 0, hi = n;  // last v with off[v] <= e
+    while (hi - lo > 1) {
+        int32_t mid = lo + ((hi - lo) >> 1);
+        if (off[mid] <= e) lo = mid;
+        else hi = mid;
+    }
+    keys[e] = ((uint64_t)(uint32_t)rank[lo] << 32) | (uint32_t)rank[adj[e]];
+}
+
+__global__ void k_keys_to_adj(int64_t m, const uint64_t *keys, int32_t *adj) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < m) adj[e] = (int32_t)(uint32_t)keys[e];
+}
+
+// mid[v] = first position of v's list holding an id > v; also raises flags
+// for self loops / duplicate arcs (bit 0) and ids out of range (bit 1).
+__global__ void k_mid_and_flags(int32_t n, const int64_t *off, const int32_t *adj, int64_t *mid, uint32_t *flags) {
+    int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    int64_t b = off[v], e = off[v + 1];
+    mid[v] = lower_bound_g(adj, b, e, v + 1);
+    uint32_t f = 0;
+    for (int64_t i = b; i < e; ++i) {
+        int32_t w = adj[i];
+        if (w == v || (i > b && w == adj[i - 1])) f |= 1u;
+    }
+    if (f) atomicOr(flags, f);
+}
+
+// Validation of caller-supplied CSR before anything dereferences it.
+__global__ void k_validate_adj(int32_t n, int64_t m, const int32_t *adj, uint32_t *flags) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < m && (adj[e] < 0 || adj[e] >= n)) atomicOr(flags, 2u);
+}
+
+__global__ void k_validate_off(int32_t n, int64_t m, const int64_t *off, uint32_t *flags) {
+    int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > n) return;
+    bool bad = off[v] < 0 || off[v] > m || (v < n && off[v] > off[v + 1]) || (v == 0 && off[0] != 0) ||
+               (v == n && off[n] != m);
+    if (bad) atomicOr(flags, 2u);
+}
+
+__global__ void k_permute_labels(int32_t n, const int32_t *perm, const uint8_t *in, uint8_t *out) {
+    int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n) out[v] = in[perm[v]];
+}
+
+// ---------------------------------------------------------------------------
+// Level 0: label / degree candidate filter over a chunk of roots
+// ---------------------------------------------------------------------------
+
+// Roots are handed out heaviest first: root index i is vertex n-1-i.  Each
+// wave compacts its survivors with one ballot and one atomic.
+__global__ void k_filter_roots(GraphView g, LevelPlan lv0, int64_t lo, int64_t hi, int32_t *rows,
+                               unsigned long long *n_rows) {
+    int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = false;
+    int32_t v = 0;
+    if (i < hi) {
+        v = (int32_t)(g.n - 1 - i);
+        ok = vertex_ok(g, lv0, v);
+    }
+    unsigned long long mask = __ballot(ok);
+    if (!mask) return;
+    int lane = lane_id();
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(n_rows, (unsigned long long)__popcll(mask));
+    base = __shfl(base, 0, GPM_WAVE);
+    if (ok) rows[base + __popcll(mask & ((1ull << lane) - 1))] = v;
+}
+
+// ---------------------------------------------------------------------------
+// Level k: candidate ranges, then load-balanced extension
+// ---------------------------------------------------------------------------
+
+// Per partial match: where its candidates start in the adjacency array and
+// how many there are (after the ordering bounds).  Also sums the merge-model
+// bytes of this level.
+__global__ void k_ranges(GraphView g, PlanView pl, int k, const int32_t *rows, int64_t nrows, int64_t *beg,
+                         int64_t *cnt, unsigned long long *alg_bytes) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t bytes = 0;
+    if (r < nrows) {
+        const int32_t *m = rows + r * k;
+        const LevelPlan &lv = pl.lv[k];
+        int64_t b, e;
+        source_range(g, lv, m, b, e);
+        beg[r] = b;
+        cnt[r] = e - b;
+        bytes = level_bytes(g, lv, m, k);
+    }
+    bytes = wave_sum_u64(bytes);
+    if (lane_id() == 0 && bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
+}
+
+// Largest b1 in (b0, nrows] such that the candidates of rows [b0, b1) fit in
+// `cap`; at least one row is always taken.
+__global__ void k_batch_end(const int64_t *pref, int64_t nrows, int64_t b0, int64_t cap, int64_t *out) {
+    int64_t base = pref[b0];
+    int64_t lo = b0 + 1, hi = nrows;  // answer in [lo, hi]
+    while (lo < hi) {
+        int64_t mid = lo + ((hi - lo + 1) >> 1);
+        if (pref[mid] - base <= cap) lo = mid;
+        else hi = mid - 1;
+    }
+    out[0] = lo;
+    out[1] = pref[lo] - base;
+}
+
+enum { MODE_EXTEND = 0, MODE_COUNT = 1, MODE_EMIT = 2 };
+
+// One thread per candidate of the concatenated candidate space [g0, g1) of
+// rows [r0, r1): perfectly balanced whatever the degree skew.  Survivors are
+// compacted per wave by ballot + prefix popcount and one atomic.
+//   MODE_EXTEND: survivors become rows of k+1 ids in `out`
+//   MODE_COUNT : survivors are only counted (last level, count-only)
+//   MODE_EMIT  : survivors complete a match, written in pattern-vertex order
+//                with the caller's 1-based ids
+template <int MODE>
+__global__ void k_extend(GraphView g, PlanView pl, int k, const int32_t *rows, const int64_t *pref, const int64_t *beg,
+                         int64_t r0, int64_t r1, int64_t g0, int64_t g1, int32_t *out, unsigned long long *n_out,
+                         const int32_t *perm) {
+    int64_t gi = g0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = false;
+    int32_t c = 0;
+    const int32_t *m = rows;
+    if (gi < g1) {
+        int64_t lo = r0, hi = r1;  // last row with pref[row] <= gi
+        while (hi - lo > 1) {
+            int64_t mid = lo + ((hi - lo) >> 1);
+            if (pref[mid] <= gi) lo = mid;
+            else hi = mid;
+        }
+        const LevelPlan &lv = pl.lv[k];
+        m = rows + lo * k;
+        c = g.adj[lv.src_dir][beg[lo] + (gi - pref[lo])];
+        ok = accept(g, lv, m, k, c);
+    }
+    unsigned long long mask = __ballot(ok);
+    if (!mask) return;
+    int lane = lane_id();
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(mask));
+    if (MODE == MODE_COUNT) return;
+    base = __shfl(base, 0, GPM_WAVE);
+    if (!ok) return;
+    unsigned long long row = base + __popcll(mask & ((1ull << lane) - 1));
+    if (MODE == MODE_EXTEND) {
+        int32_t *o = out + row * (k + 1);
+        for (int t = 0; t < k; ++t) o[t] = m[t];
+        o[k] = c;
+    } else {
+        int32_t *o = out + row * pl.P;
+        for (int t = 0; t < k; ++t) o[pl.order[t]] = perm[m[t]] + 1;
+        o[pl.order[k]] = perm[c] + 1;
+    }
+}
+
+// Single-vertex pattern in output mode: every surviving root is a match.
+__global__ void k_emit_roots(int64_t nrows, const int32_t *rows, const int32_t *perm, int32_t *out) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nrows) out[r] = perm[rows[r]] + 1;
+}
+
+// ---------------------------------------------------------------------------
+// Fused last two levels: neighbour-list intersection staged through LDS
+// ---------------------------------------------------------------------------
+
+#define TAIL_WAVES 4
+#define TAIL_CAP 1024  // ids of one wave's staged candidate set (4 KiB)
+
+// How the second-to-last level (A) and the last level (B) relate.  When
+// `reuse` is set, B's operand lists are A's lists plus the lists owned by the
+// A vertex itself, so B's candidates are (A's survivor set) intersected with
+// those extra lists: the staged set is probed in LDS instead of re-reading
+// A's lists from memory for every A vertex.
+struct TailInfo {
+    int8_t reuse;
+    int8_t n_extra;         // lists of level B owned by the A vertex (1 or 2)
+    int8_t extra_dir[2], extra_part[2];
+    int8_t b_lower_is_a;    // B requires c > a (a is B's largest lower bound)
+    int8_t b_upper_is_a;    // B requires c < a
+    int8_t any_shortest;    // simple graph: level A may walk its shortest list
+};
+
+// Count |{c in staged[sb, se) : c in every extra list of a, c != a}|, where
+// the wave either walks the staged set and probes a's list in memory, or
+// streams a's list with coalesced reads and probes the staged set in LDS,
+// whichever side is shorter.
+__device__ __forceinline__ uint32_t tail_reuse_count(const GraphView &g, const TailInfo &ti, const int32_t *staged,
+                                                     int sb, int se, int32_t a, int lane) {
+    uint32_t cnt = 0;
+    int64_t b0, e0;
+    list_range(g, ti.extra_dir[0], ti.extra_part[0], a, b0, e0);
+    const int32_t *adj0 = g.adj[ti.extra_dir[0]];
+    int64_t b1 = 0, e1 = 0;
+    const int32_t *adj1 = nullptr;
+    if (ti.n_extra > 1) {
+        list_range(g, ti.extra_dir[1], ti.extra_part[1], a, b1, e1);
+        adj1 = g.adj[ti.extra_dir[1]];
+    }
+    if ((int64_t)(se - sb) <= e0 - b0) {
+        for (int i = sb + lane; i < se; i += GPM_WAVE) {
+            int32_t c = staged[i];
+            bool ok = c != a && contains_g(adj0, b0, e0, c);
+            if (ok && adj1) ok = contains_g(adj1, b1, e1, c);
+            cnt += ok;
+        }
+    } else {
+        // narrow a's list to the id window of the staged range first
+        int32_t first = staged[sb], last = staged[se - 1];
+        b0 = lower_bound_g(adj0, b0, e0, first);
+        e0 = lower_bound_g(adj0, b0, e0, last + 1);
+        for (int64_t i = b0 + lane; i < e0; i += GPM_WAVE) {
+            int32_t c = adj0[i];
+            int p = lower_bound_s(staged, sb, se, c);
+            bool ok = p < se && staged[p] == c && c != a;
+            if (ok && adj1) ok = contains_g(adj1, b1, e1, c);
+            cnt += ok;
+        }
+    }
+    return cnt;
+}
+
+// One wave per partial match of length L = P-2.  Level A survivors are
+// compacted into the wave's LDS slice (ballot + prefix popcount); level B is
+// evaluated per survivor and only counted.
+__global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, PlanView pl, TailInfo ti,
+                                                               const int32_t *rows, int64_t nrows,
+                                                               unsigned long long *n_matches,
+                                                               unsigned long long *alg_bytes) {
+    __shared__ int32_t s_set[TAIL_WAVES][TAIL_CAP];
+    __shared__ int32_t s_m[TAIL_WAVES][GPM_MAXP + 2];
+    const int wave = threadIdx.x / GPM_WAVE, lane = lane_id();
+    const int L = pl.P - 2;
+    const LevelPlan &la = pl.lv[L];
+    const LevelPlan &lb = pl.lv[L + 1];
+    int32_t *staged = s_set[wave];
+    int32_t *m = s_m[wave];
+    uint64_t cnt = 0, bytes = 0;
+
+    for (int64_t r = (int64_t)blockIdx.x * TAIL_WAVES + wave; r < nrows; r += (int64_t)gridDim.x * TAIL_WAVES) {
+        wave_lds_sync();
+        if (lane < L) m[lane] = rows[r * L + lane];
+        wave_lds_sync();
+        if (lane == 0) bytes += level_bytes(g, la, m, L);
+
+        // Level A: walk the source list, or on a simple graph whichever
+        // operand list is shortest (the result set is the same).  The
+        // ordering bounds cut the source range exactly; on another list they
+        // are tested per element.
+        int walk = -1;  // -1 = source list, j = constraint j
+        int64_t b, e;
+        source_range(g, la, m, b, e);
+        int32_t lo_id = -1, hi_id = INT32_MAX;
+        if (ti.any_shortest) {
+            for (int j = 0; j < la.n_cons; ++j) {
+                int64_t cb, ce;
+                list_range(g, la.cons_dir[j], la.cons_part[j], m[la.cons_level[j]], cb, ce);
+                if (ce - cb < e - b) {
+                    b = cb;
+                    e = ce;
+                    walk = j;
+                }
+            }
+            if (walk >= 0) {
+                for (int j = 0; j < la.n_lower; ++j) lo_id = max(lo_id, m[la.lower_level[j]]);
+                for (int j = 0; j < la.n_upper; ++j) hi_id = min(hi_id, m[la.upper_level[j]]);
+            }
+        }
+        const int32_t *wadj = g.adj[walk < 0 ? la.src_dir : la.cons_dir[walk]];
+        const bool reuse_row = ti.reuse && (e - b) <= TAIL_CAP;
+
+        int n_staged = 0;
+        for (int64_t i0 = b; i0 < e; i0 += GPM_WAVE) {
+            int64_t i = i0 + lane;
+            bool ok = false;
+            int32_t c = 0;
+            if (i < e) {
+                c = wadj[i];
+                ok = c > lo_id && c < hi_id && accept(g, la, m, L, c, walk);
+            }
+            unsigned long long mask = __ballot(ok);
+            if (ok) staged[n_staged + __popcll(mask & ((1ull << lane) - 1))] = c;
+            n_staged += __popcll(mask);
+            bool last = i0 + GPM_WAVE >= e;
+            if (!last && (reuse_row || n_staged + GPM_WAVE <= TAIL_CAP)) continue;
+            wave_lds_sync();
+            // level B for every staged survivor a
+            for (int ia = 0; ia < n_staged; ++ia) {
+                int32_t a = staged[ia];
+                if (reuse_row) {
+                    int sb = ti.b_lower_is_a ? ia + 1 : 0;
+                    int se = ti.b_upper_is_a ? ia : n_staged;
+                    m[L] = a;  // same value from every lane
+                    wave_lds_sync();
+                    if (lane == 0) bytes += level_bytes(g, lb, m, L + 1);
+                    if (se > sb) cnt += tail_reuse_count(g, ti, staged, sb, se, a, lane);
+                } else {
+                    m[L] = a;
+                    wave_lds_sync();
+                    if (lane == 0) bytes += level_bytes(g, lb, m, L + 1);
+                    int64_t b2, e2;
+                    source_range(g, lb, m, b2, e2);
+                    const int32_t *badj = g.adj[lb.src_dir];
+                    for (int64_t i2 = b2 + lane; i2 < e2; i2 += GPM_WAVE) cnt += accept(g, lb, m, L + 1, badj[i2]);
+                }
+            }
+            n_staged = 0;
+            wave_lds_sync();
+        }
+    }
+    cnt = wave_sum_u64(cnt);
+    bytes = wave_sum_u64(bytes);
+    if (lane == 0) {
+        if (cnt) atomicAdd(n_matches, (unsigned long long)cnt);
+        if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
+    }
+}

@@ -1,0 +1,218 @@
+#include "plan.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "utils.h"
+
+static int planFail(char *err, int errLen, const char *msg) {
+    if (err && errLen > 0) snprintf(err, (size_t)errLen, "%s", msg);
+    return -1;
+}
+
+/* Preorder numbering from vertex v (0-based): out-neighbours in listing order
+ * first, then in-neighbours in ascending source order; a vertex first reached
+ * along an in-edge gets a negative number (reference: dfs, src/graph.c:7-22). */
+static int numberFrom(const Pattern *p, int v, int parent, int id, int *num, int32_t *parents, int viaInEdge) {
+    num[v] = viaInEdge ? -id : id;
+    parents[v] = parent;
+    for (int j = 0; j < p->outDegrees[v]; ++j) {
+        int w = p->outEdges[v][j];
+        if (num[w] == 0) id = numberFrom(p, w, v, id + 1, num, parents, 0);
+    }
+    for (int j = 0; j < p->inDegrees[v]; ++j) {
+        int w = p->inEdges[v][j];
+        if (num[w] == 0) id = numberFrom(p, w, v, id + 1, num, parents, 1);
+    }
+    return id;
+}
+
+int makeGraphOrdering(const Pattern *p, int32_t ordering[MAX_MATCH_SIZE + 1], int32_t parents[MAX_MATCH_SIZE + 1]) {
+    int num[MAX_MATCH_SIZE] = {0};
+    int32_t par0[MAX_MATCH_SIZE];
+    memset(ordering, 0, (MAX_MATCH_SIZE + 1) * sizeof(int32_t));
+    memset(parents, 0, (MAX_MATCH_SIZE + 1) * sizeof(int32_t));
+    int reached = numberFrom(p, 0, -1, 1, num, par0, 0);
+    for (int v = 0; v < p->nodesCount; ++v) {
+        if (num[v] == 0) continue;
+        /* reference: src/graph.c:28-34, ids shifted back to 1-based */
+        ordering[abs(num[v])] = num[v] > 0 ? v + 1 : -(v + 1);
+        parents[v + 1] = par0[v] < 0 ? -1 : par0[v] + 1;
+    }
+    return reached == p->nodesCount ? 0 : -1;
+}
+
+/* ---- automorphisms and symmetry breaking ----------------------------- */
+
+typedef struct {
+    int P;
+    unsigned char adj[MAX_MATCH_SIZE][MAX_MATCH_SIZE]; /* arc a->b, a != b, duplicates collapsed */
+    int32_t label[MAX_MATCH_SIZE];
+    int8_t *tab; /* n * P */
+    uint64_t n, cap;
+} AutSearch;
+
+static void autRec(AutSearch *s, int i, int8_t *perm, unsigned used) {
+    int P = s->P;
+    if (i == P) {
+        if (s->n == s->cap) {
+            s->cap = s->cap ? s->cap * 2 : 64;
+            s->tab = safeRealloc(s->tab, (size_t)s->cap * (size_t)P);
+        }
+        memcpy(s->tab + s->n * (uint64_t)P, perm, (size_t)P);
+        s->n++;
+        return;
+    }
+    for (int c = 0; c < P; ++c) {
+        if (used >> c & 1u) continue;
+        if (s->label[c] != s->label[i]) continue;
+        int ok = 1;
+        for (int j = 0; j < i && ok; ++j)
+            ok = s->adj[i][j] == s->adj[c][perm[j]] && s->adj[j][i] == s->adj[perm[j]][c];
+        if (!ok) continue;
+        perm[i] = (int8_t)c;
+        autRec(s, i + 1, perm, used | 1u << c);
+    }
+}
+
+/* Ordering conditions lt[a][b] (bind m(a) < m(b)) that keep exactly one member
+ * of every class of automorphic matches: repeatedly take the earliest-bound
+ * vertex v that the remaining automorphisms still move, require m(v) to be
+ * the smallest over v's orbit, and keep only the automorphisms that fix v. */
+static void breakSymmetry(const AutSearch *s, const int32_t *order, unsigned char lt[MAX_MATCH_SIZE][MAX_MATCH_SIZE]) {
+    int P = s->P;
+    uint64_t n = s->n;
+    unsigned char *alive = safeMalloc((size_t)n);
+    memset(alive, 1, (size_t)n);
+    memset(lt, 0, MAX_MATCH_SIZE * MAX_MATCH_SIZE);
+    for (;;) {
+        int chosen = -1;
+        unsigned orbit = 0;
+        for (int k = 0; k < P && chosen < 0; ++k) {
+            int v = order[k];
+            unsigned o = 0;
+            for (uint64_t i = 0; i < n; ++i)
+                if (alive[i]) o |= 1u << s->tab[i * (uint64_t)P + (uint64_t)v];
+            if (o != 1u << v) {
+                chosen = v;
+                orbit = o;
+            }
+        }
+        if (chosen < 0) break;
+        for (int u = 0; u < P; ++u)
+            if (u != chosen && (orbit >> u & 1u)) lt[chosen][u] = 1;
+        for (uint64_t i = 0; i < n; ++i)
+            if (alive[i] && s->tab[i * (uint64_t)P + (uint64_t)chosen] != chosen) alive[i] = 0;
+    }
+    free(alive);
+}
+
+int buildPlan(const Pattern *p, int flags, gpm_plan *plan, char *err, int errLen) {
+    int P = p->nodesCount;
+    memset(plan, 0, sizeof *plan);
+    if (P < 1 || P > MAX_MATCH_SIZE) return planFail(err, errLen, "pattern must have 1..10 vertices");
+    int32_t ordering[MAX_MATCH_SIZE + 1], parents[MAX_MATCH_SIZE + 1];
+    if (makeGraphOrdering(p, ordering, parents) != 0)
+        return planFail(err, errLen, "pattern is not connected from vertex 1");
+
+    int levelOf[MAX_MATCH_SIZE];
+    plan->n_levels = P;
+    plan->n_aut = 1;
+    for (int k = 0; k < P; ++k) {
+        plan->order[k] = abs(ordering[k + 1]) - 1;
+        levelOf[plan->order[k]] = k;
+    }
+    int symData = (flags & PLAN_SYMMETRIC_DATA) != 0;
+
+    /* effective pattern arcs: self loops never constrain anything (the vertex
+     * is still unbound when it is tested, reference: src/gpm-par.c:96-97) */
+    AutSearch as;
+    memset(&as, 0, sizeof as);
+    as.P = P;
+    for (int v = 0; v < P; ++v) {
+        as.label[v] = p->hasLabels ? p->labels[v] : -1;
+        for (int j = 0; j < p->outDegrees[v]; ++j)
+            if (p->outEdges[v][j] != v) as.adj[v][p->outEdges[v][j]] = 1;
+    }
+
+    for (int k = 0; k < P; ++k) {
+        int pv = plan->order[k];
+        plan->label[k] = p->hasLabels ? p->labels[pv] : -1;
+        int dOut = 0, dIn = 0;
+        for (int t = 0; t < P; ++t) {
+            dOut += as.adj[pv][t];
+            dIn += as.adj[t][pv];
+        }
+        if (flags & PLAN_DEGREE_FILTER) {
+            plan->min_out_deg[k] = dOut;
+            plan->min_in_deg[k] = dIn;
+        }
+        if (k == 0) {
+            plan->src_level[0] = -1;
+            continue;
+        }
+        int parent = parents[pv + 1] - 1;
+        int srcDir = ordering[k + 1] < 0 ? 1 : 0; /* reached through an in-edge: walk the parent's in-list */
+        plan->src_level[k] = levelOf[parent];
+        plan->src_dir[k] = symData ? 0 : srcDir;
+        /* every bound pattern neighbour t constrains the candidate c:
+         *   arc pv->t : m(t) in N_out(c)  <=>  c in N_in(m(t))
+         *   arc t->pv : m(t) in N_in(c)   <=>  c in N_out(m(t))
+         * (reference: src/gpm-par.c:94-110; in-lists are the exact transpose) */
+        int nc = 0;
+        for (int lt = 0; lt < k; ++lt) {
+            int t = plan->order[lt];
+            for (int dir = 0; dir < 2; ++dir) {
+                int has = dir == 0 ? as.adj[t][pv] : as.adj[pv][t];
+                if (!has) continue;
+                int d = symData ? 0 : dir;
+                if (lt == plan->src_level[k] && d == plan->src_dir[k]) continue; /* the tree edge itself */
+                int dup = 0;
+                for (int j = 0; j < nc; ++j) dup |= plan->cons_level[k][j] == lt && plan->cons_dir[k][j] == d;
+                if (dup) continue;
+                plan->cons_level[k][nc] = lt;
+                plan->cons_dir[k][nc] = d;
+                nc++;
+            }
+        }
+        plan->n_cons[k] = nc;
+    }
+
+    if (flags & PLAN_BREAK_SYMMETRY) {
+        int8_t perm[MAX_MATCH_SIZE];
+        autRec(&as, 0, perm, 0);
+        if (as.n > 1) {
+            unsigned char lt[MAX_MATCH_SIZE][MAX_MATCH_SIZE], closure[MAX_MATCH_SIZE][MAX_MATCH_SIZE];
+            breakSymmetry(&as, plan->order, lt);
+            memcpy(closure, lt, sizeof closure);
+            for (int m = 0; m < P; ++m)
+                for (int a = 0; a < P; ++a)
+                    for (int b = 0; b < P; ++b) closure[a][b] |= closure[a][m] & closure[m][b];
+            for (int k = 1; k < P; ++k) {
+                int u = plan->order[k], nl = 0;
+                for (int a = 0; a < P; ++a) {
+                    if (!lt[a][u]) continue;
+                    int implied = 0; /* a < w < u for another direct bound w */
+                    for (int w = 0; w < P; ++w) implied |= w != a && lt[w][u] && closure[a][w];
+                    if (!implied) plan->lower_level[k][nl++] = levelOf[a];
+                }
+                plan->n_lower[k] = nl;
+            }
+            /* move the identity to the front */
+            for (uint64_t i = 0; i < as.n; ++i) {
+                int id = 1;
+                for (int v = 0; v < P; ++v) id &= as.tab[i * (uint64_t)P + (uint64_t)v] == v;
+                if (id && i != 0) {
+                    memcpy(as.tab + i * (uint64_t)P, as.tab, (size_t)P);
+                    for (int v = 0; v < P; ++v) as.tab[v] = (int8_t)v;
+                }
+            }
+            plan->n_aut = as.n;
+            plan->aut = as.tab;
+            as.tab = NULL;
+        }
+        free(as.tab);
+    }
+    return 0;
+}

@@ -1,0 +1,200 @@
+"""Parity of the HIP path with the oracle and the golden vectors, through the
+C ABI (libgpm_hip.so) and through the drop-in program (gpm-par.exe).
+
+Bar: bit-exact -- equal counts and equal sorted multisets of output lines
+(the reference's own line order is arrival order and unspecified)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mpi_amd import binding, gen
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+EXE = os.path.join(util.ROOT, "gpm-par.exe")
+GOLDEN = util.golden_specs()
+ROWS_MAX = 2_000_000  # full multiset check up to this many matches; counts beyond
+
+
+def csr_of(n, s, d):
+    """Both CSR directions (sorted lists) from 0-based arcs."""
+    s = np.asarray(s, dtype=np.int64)
+    d = np.asarray(d, dtype=np.int64)
+
+    def one(a, b):
+        order = np.lexsort((b, a))
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(off, a + 1, 1)
+        return np.cumsum(off), b[order].astype(np.int32)
+
+    oo, oa = one(s, d)
+    io, ia = one(d, s)
+    return oo, oa, io, ia
+
+
+def upload(m, n, s, d, labels=None):
+    oo, oa, io, ia = csr_of(n, s, d)
+    fwd = set(zip(np.asarray(s).tolist(), np.asarray(d).tolist()))
+    symmetric = all((b, a) in fwd for a, b in fwd)
+    if symmetric:
+        return m.upload(n, oo, oa, labels=labels)
+    return m.upload(n, oo, oa, io, ia, labels=labels)
+
+
+def run_cli(text, tmp_path, env=None):
+    i, o = tmp_path / "in.txt", tmp_path / "out.txt"
+    i.write_text(text)
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([EXE, str(i), str(o)], capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0, r.stderr
+    return r, o.read_bytes()
+
+
+@pytest.mark.parametrize("name", util.small_cases())
+def test_cli_small_cases(name, tmp_path):
+    inp, out = util.small_paths(name)
+    r, got = run_cli(open(inp).read(), tmp_path)
+    want = open(out, "rb").read()
+    assert sorted(got.splitlines()) == sorted(want.splitlines())
+    lines = r.stdout.splitlines()
+    assert len(lines) == 2
+    assert lines[0].startswith("Distribution time[s]: ") and lines[0].split(": ")[1].isdigit()
+    assert lines[1].startswith("Computations time[s]: ") and lines[1].split(": ")[1].isdigit()
+
+
+@pytest.mark.parametrize("name", ["t1", "dup_edge", "reverse_plan"])
+def test_cli_under_an_mpi_style_launch(name, tmp_path):
+    """rank 0 does the work, other ranks exit at once: the output is written once."""
+    inp, out = util.small_paths(name)
+    _, got = run_cli(open(inp).read(), tmp_path, env={"PMI_RANK": "0"})
+    assert sorted(got.splitlines()) == sorted(open(out, "rb").read().splitlines())
+
+
+@pytest.mark.parametrize("spec", GOLDEN, ids=[g["name"] for g in GOLDEN])
+def test_golden_counts_and_multisets(spec):
+    n, s, d = util.build_graph(spec)
+    dl, pl = util.build_labels(spec, n)
+    m = binding.Matcher(1)
+    upload(m, n, s, d, labels=dl)
+    m.set_pattern(gen.PATTERNS[spec["pattern"]], labels=pl)
+    assert m.findMatches(count_only=True) == spec["count"]
+    if spec["count"] <= ROWS_MAX:
+        rows = m.findMatches(count_only=False)
+        assert len(rows) == spec["count"]
+        assert util.sorted_lines_md5(util.rows_to_text(rows)) == spec["sorted_md5"]
+    m.close()
+
+
+CLI_GOLDEN = [g for g in GOLDEN if g["name"] in ("er10k_triangle", "rmat10_clique4", "rmat8_house",
+                                                 "plaw9_tree5_labelled4", "rand40_dir_tree5_dir")]
+
+
+@pytest.mark.parametrize("spec", CLI_GOLDEN, ids=[g["name"] for g in CLI_GOLDEN])
+def test_cli_golden_files(spec, tmp_path):
+    text, _, _ = util.build_input(spec)
+    _, got = run_cli(text, tmp_path)
+    assert got.count(b"\n") == spec["count"]
+    assert util.sorted_lines_md5(got) == spec["sorted_md5"]
+
+
+VARIANTS = [
+    {"symbreak": True, "env": {}},
+    {"symbreak": False, "env": {}},
+    {"symbreak": True, "env": {"GPM_NO_TAIL": "1"}},
+    {"symbreak": False, "env": {"GPM_NO_TAIL": "1"}},
+    {"symbreak": True, "env": {"GPM_NO_REUSE": "1"}},
+    {"symbreak": True, "env": {"GPM_ARENA_ROWS": "4096", "GPM_CHUNK_ROOTS": "64", "GPM_EMIT_ROWS": "1000"}},
+]
+VAR_SPECS = [g for g in GOLDEN if g["name"] in (
+    "rand9_sym_clique4", "rand9_sym_cycle4", "rand9_dir_tree5_dir", "rand40_dir_rev4", "rand40_dir_k4_dag",
+    "rmat8_triangle", "rmat8_clique4", "rmat8_cycle4", "rmat8_house", "rmat8_clique5", "skew8_k6_minus_e",
+    "plaw9_tree5_labelled4", "er10k_triangle")]
+
+
+@pytest.mark.parametrize("variant", range(len(VARIANTS)))
+@pytest.mark.parametrize("spec", VAR_SPECS, ids=[g["name"] for g in VAR_SPECS])
+def test_every_device_path_agrees(spec, variant, monkeypatch):
+    """Symmetry breaking on/off, fused tail on/off, LDS reuse on/off and a tiny
+    arena that forces batch splitting all give the golden count and multiset."""
+    v = VARIANTS[variant]
+    for k, val in v["env"].items():
+        monkeypatch.setenv(k, val)
+    n, s, d = util.build_graph(spec)
+    dl, pl = util.build_labels(spec, n)
+    m = binding.Matcher(1)
+    upload(m, n, s, d, labels=dl)
+    m.set_pattern(gen.PATTERNS[spec["pattern"]], labels=pl, symbreak=v["symbreak"])
+    assert m.findMatches(count_only=True) == spec["count"]
+    if spec["count"] <= 300_000:
+        rows = m.findMatches(count_only=False)
+        assert util.sorted_lines_md5(util.rows_to_text(rows)) == spec["sorted_md5"]
+    m.close()
+
+
+def test_algorithmic_bytes_equal_the_oracle_model():
+    """Without ordering bounds the device's merge-model byte count is the oracle's plus 4 bytes per root."""
+    for name in ("rmat8_clique4", "rmat8_cycle4", "rand40_dir_rev4"):
+        spec = next(g for g in GOLDEN if g["name"] == name)
+        n, s, d = util.build_graph(spec)
+        _, _, ost = util.oracle_matches(n, s, d, gen.PATTERNS[spec["pattern"]], want_rows=False)
+        m = binding.Matcher(1)
+        upload(m, n, s, d)
+        m.set_pattern(gen.PATTERNS[spec["pattern"]], symbreak=False, degree_filter=False)
+        assert m.findMatches(count_only=True) == spec["count"]
+        st = m.stats()
+        assert st.alg_bytes == ost.alg_bytes + 4 * n
+        m.close()
+
+
+def test_root_shards_sum_to_the_whole():
+    """Linearity over root ranges: what multi-GPU sharding relies on."""
+    n, s, d = util.build_graph({"graph": "rmat", "scale": 12, "ef": 8, "seed": 1})
+    m = binding.Matcher(1)
+    upload(m, n, s, d)
+    m.set_pattern(gen.PATTERNS["clique4"])
+    whole = m.findMatches(count_only=True)
+    cuts = [0, 1, 100, 1000, 2048, n]
+    parts = 0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        m.set_roots(lo, hi)
+        parts += m.findMatches(count_only=True)
+    assert parts == whole
+    m.close()
+
+
+@pytest.mark.parametrize("pname", ["triangle", "clique4", "cycle4", "diamond", "clique5"])
+def test_mid_size_properties(pname):
+    """R-MAT scale 14: all four device paths agree with each other and with the oracle."""
+    n, s, d = util.build_graph({"graph": "rmat", "scale": 13, "ef": 8, "seed": 3})
+    want = None
+    if pname in ("triangle", "clique4"):
+        want, _, _ = util.oracle_matches(n, s, d, gen.PATTERNS[pname], want_rows=False)
+    m = binding.Matcher(1)
+    upload(m, n, s, d)
+    counts = []
+    for symbreak in (True, False):
+        m.set_pattern(gen.PATTERNS[pname], symbreak=symbreak)
+        counts.append(m.findMatches(count_only=True))
+    m.close()
+    assert counts[0] == counts[1]
+    if want is not None:
+        assert counts[0] == want
+
+
+def test_bad_arguments_are_rejected():
+    m = binding.Matcher(1)
+    off = np.array([0, 2, 1], dtype=np.int64)  # not monotone
+    adj = np.array([1, 0], dtype=np.int32)
+    with pytest.raises(binding.GpmError):
+        m.upload(2, off, adj)
+    off = np.array([0, 1, 2], dtype=np.int64)
+    adj = np.array([1, 7], dtype=np.int32)  # id out of range
+    with pytest.raises(binding.GpmError):
+        m.upload(2, off, adj)
+    with pytest.raises(binding.GpmError):
+        m.findMatches()  # nothing uploaded
+    m.close()

@@ -1,0 +1,205 @@
+"""Host C code (parser, CSR builder, planner) and the drop-in boundary,
+checked without a GPU."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mpi_amd import binding, gen
+from tests import planref, util
+
+PATTERN_NAMES = sorted(gen.PATTERNS)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    lib = binding.hip_lib()
+    header = open(os.path.join(util.ROOT, "include", "gpm_hip.h")).read()
+    import re
+    declared = sorted(set(re.findall(r"\b(gpm_hip_[a-z_]+)\s*\(", header)))
+    assert declared == sorted(binding.HIP_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_missing_gpu_is_reported_not_hidden():
+    lib = binding.hip_lib()
+    if lib.gpm_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(binding.GpmError):
+        binding.Matcher(1)
+
+
+@pytest.mark.parametrize("name", util.small_cases())
+def test_parser_matches_oracle_parser(name, tmp_path):
+    inp, _ = util.small_paths(name)
+    data, pat = binding.readGraph(inp)
+    lib = util.oracle_lib()
+    lib.oracle_parse_file.argtypes = [ctypes.c_char_p] + [ctypes.POINTER(ctypes.c_void_p)] * 4
+
+    class OG(ctypes.Structure):
+        _fields_ = [("n", ctypes.c_int), ("out", ctypes.POINTER(ctypes.POINTER(ctypes.c_int))),
+                    ("outdeg", ctypes.POINTER(ctypes.c_int)), ("inn", ctypes.POINTER(ctypes.POINTER(ctypes.c_int))),
+                    ("indeg", ctypes.POINTER(ctypes.c_int)), ("ordering", ctypes.POINTER(ctypes.c_int)),
+                    ("parents", ctypes.POINTER(ctypes.c_int))]
+
+    g, p, dl, pl = (ctypes.c_void_p() for _ in range(4))
+    assert lib.oracle_parse_file(inp.encode(), ctypes.byref(g), ctypes.byref(p), ctypes.byref(dl),
+                                 ctypes.byref(pl)) == 0
+    og = ctypes.cast(g, ctypes.POINTER(OG)).contents
+    assert og.n == data["n"]
+    for v in range(og.n):
+        want_out = sorted(og.out[v + 1][j] - 1 for j in range(og.outdeg[v + 1]))
+        want_in = sorted(og.inn[v + 1][j] - 1 for j in range(og.indeg[v + 1]))
+        assert data["out_adj"][data["out_off"][v]:data["out_off"][v + 1]].tolist() == want_out
+        assert data["in_adj"][data["in_off"][v]:data["in_off"][v + 1]].tolist() == want_in
+    # the plan arrays equal the oracle's restatement of the reference's
+    op = ctypes.cast(p, ctypes.POINTER(OG)).contents
+    o, par, ok = binding.makeGraphOrdering(pat)
+    assert ok
+    assert o[1:op.n + 1].tolist() == [op.ordering[k] for k in range(1, op.n + 1)]
+    assert par[1:op.n + 1].tolist() == [op.parents[v] for v in range(1, op.n + 1)]
+    binding.host_lib().freePattern(pat)
+
+
+def test_parser_rejects_bad_input(tmp_path):
+    bad = {
+        "id_out_of_range": "3\n1 1\n4\n\n2\n1 1\n2\n",
+        "truncated_list": "3\n1 2\n2\n",
+        "listed_twice": "3\n1 1\n2\n1 1\n3\n\n2\n1 1\n2\n",
+        "pattern_too_large": "3\n1 1\n2\n\n11\n1 1\n2\n",
+        "garbage_header": "x\n",
+    }
+    for name, text in bad.items():
+        p = tmp_path / (name + ".in")
+        p.write_text(text)
+        with pytest.raises(binding.GpmError):
+            binding.readGraph(str(p))
+
+
+def test_symmetric_and_simple_flags(tmp_path):
+    p = tmp_path / "a.in"
+    p.write_text("3\n1 2\n2\n3\n2 1\n1\n3 1\n1\n\n2\n1 1\n2\n")
+    data, pat = binding.readGraph(str(p))
+    assert data["symmetric"] and data["simple"]
+    binding.host_lib().freePattern(pat)
+    inp, _ = util.small_paths("dup_edge")
+    data, pat = binding.readGraph(inp)
+    assert not data["simple"] and not data["symmetric"]
+    binding.host_lib().freePattern(pat)
+
+
+@pytest.mark.parametrize("pname", PATTERN_NAMES)
+def test_plan_order_equals_reference_order(pname):
+    """ordering/parents from the C planner == the oracle's restatement of graph.c:7-36."""
+    pat = gen.PATTERNS[pname]
+    p = binding.make_pattern(pat)
+    o, par, ok = binding.makeGraphOrdering(p)
+    binding.host_lib().freePattern(p)
+    lib = util.oracle_lib()
+    P, arcs = pat
+    ps = np.array([a for a, _ in arcs], dtype=np.int32)
+    pd = np.array([b for _, b in arcs], dtype=np.int32)
+    og = lib.oracle_graph_from_edges(P, ps.ctypes.data, pd.ctypes.data, len(ps))
+    assert (lib.oracle_make_plan(og) == 0) == ok
+
+    class OG(ctypes.Structure):
+        _fields_ = [("n", ctypes.c_int), ("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("c", ctypes.c_void_p),
+                    ("d", ctypes.c_void_p), ("ordering", ctypes.POINTER(ctypes.c_int)),
+                    ("parents", ctypes.POINTER(ctypes.c_int))]
+
+    g = ctypes.cast(og, ctypes.POINTER(OG)).contents
+    assert o[1:P + 1].tolist() == [g.ordering[k] for k in range(1, P + 1)]
+    assert par[1:P + 1].tolist() == [g.parents[v] for v in range(1, P + 1)]
+    lib.oracle_graph_free(og)
+
+
+def test_disconnected_pattern_is_rejected():
+    p = binding.make_pattern((3, [(1, 2)]))
+    with pytest.raises(binding.GpmError):
+        binding.make_plan(p, 0)
+    binding.host_lib().freePattern(p)
+
+
+N_AUT = {"edge": 1, "edge_und": 2, "tri_dir": 3, "triangle": 6, "path3": 2, "cycle4": 8, "clique4": 24,
+         "diamond": 4, "k4_dag": 1, "rev4": 1, "tree5": 2, "tree5_dir": 1, "clique5": 120, "house": 2,
+         "k6_minus_pm": 48, "k6_minus_e": 48}
+
+
+@pytest.mark.parametrize("pname", PATTERN_NAMES)
+def test_automorphism_counts(pname):
+    p = binding.make_pattern(gen.PATTERNS[pname])
+    plan = binding.make_plan(p, binding.PLAN_BREAK_SYMMETRY)
+    binding.host_lib().freePattern(p)
+    assert plan.n_aut == N_AUT[pname]
+
+
+@pytest.mark.parametrize("pname", PATTERN_NAMES)
+@pytest.mark.parametrize("symmetric", [False, True])
+@pytest.mark.parametrize("symbreak", [False, True])
+def test_plan_semantics_equal_oracle(pname, symmetric, symbreak):
+    """Interpreting the C planner's plan in Python gives the oracle's match multiset,
+    with and without symmetry breaking."""
+    n = 10 if gen.PATTERNS[pname][0] <= 5 else 9
+    s, d = util.rand_digraph(n, 55 if gen.PATTERNS[pname][0] >= 5 else 40, 100, 5, symmetric)
+    pat = gen.PATTERNS[pname]
+    cnt, rows, _ = util.oracle_matches(n, s, d, pat, fast=1)
+    flags = (binding.PLAN_SYMMETRIC_DATA if symmetric else 0) | binding.PLAN_DEGREE_FILTER
+    if symbreak:
+        flags |= binding.PLAN_BREAK_SYMMETRY
+    p = binding.make_pattern(pat)
+    plan = binding.make_plan(p, flags)
+    binding.host_lib().freePattern(p)
+    out, inn = planref.csr_lists(n, s, d)
+    canon = planref.run_plan(plan, n, out, inn, symmetric=symmetric)
+    assert len(canon) * plan.n_aut == cnt
+    got = sorted(tuple(x + 1 for x in r) for r in planref.expand_automorphisms(plan, canon))
+    assert got == sorted(map(tuple, rows.tolist()))
+
+
+def test_labelled_plan_semantics():
+    n = 12
+    s, d = util.rand_digraph(n, 45, 100, 9, True)
+    dl = gen.vertex_labels(n, 3, seed=4).numpy().astype(np.int32)
+    pl = [0, 1, 2, 1, 1]
+    pat = gen.PATTERNS["tree5"]
+    cnt, rows, _ = util.oracle_matches(n, s, d, pat, data_labels=dl, pattern_labels=pl)
+    p = binding.make_pattern(pat, labels=pl)
+    plan = binding.make_plan(p, binding.PLAN_SYMMETRIC_DATA | binding.PLAN_BREAK_SYMMETRY | binding.PLAN_DEGREE_FILTER)
+    binding.host_lib().freePattern(p)
+    out, inn = planref.csr_lists(n, s, d)
+    canon = planref.run_plan(plan, n, out, inn, labels=dl, symmetric=True)
+    assert len(canon) * plan.n_aut == cnt
+    got = sorted(tuple(x + 1 for x in r) for r in planref.expand_automorphisms(plan, canon))
+    assert got == sorted(map(tuple, rows.tolist()))
+
+
+# ---- the program's command line (reference: checkArgs, src/gpm-par.c:49-69) ----
+
+EXE = os.path.join(util.ROOT, "gpm-par.exe")
+
+
+def run_exe(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([EXE] + args, capture_output=True, text=True, env=e, timeout=120)
+
+
+def test_cli_wrong_argc():
+    r = run_exe([])
+    assert r.returncode == 1
+    assert r.stderr == "ERROR: files not specified\n"
+    r = run_exe(["a", "b", "c"])
+    assert r.returncode == 1 and r.stderr == "ERROR: files not specified\n"
+
+
+def test_cli_missing_input(tmp_path):
+    r = run_exe([str(tmp_path / "nope.txt"), str(tmp_path / "out.txt")])
+    assert r.returncode == 1
+    assert r.stderr == f"ERROR: file not found {tmp_path / 'nope.txt'}\n"
+
+
+def test_cli_nonzero_mpi_ranks_exit_quietly(tmp_path):
+    r = run_exe([], env={"PMI_RANK": "1"})
+    assert r.returncode == 0 and r.stderr == "" and r.stdout == ""
