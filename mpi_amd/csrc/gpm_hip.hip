@@ -138,6 +138,15 @@ extern "C" int gpm_hip_device_count(void) {
     return n;
 }
 
+// Null-safe frees: freeing a null pointer would leave a sticky HIP error that
+// the next library call (rocprim checks hipGetLastError) would trip over.
+static void dev_free(void *p) {
+    if (p) (void)hipFree(p);
+}
+static void host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 static void free_graph(DevState &d) {
     (void)hipSetDevice(d.dev);
     for (int dir = 0; dir < 2; ++dir) {
@@ -146,15 +155,15 @@ static void free_graph(DevState &d) {
             d.adj[1] = nullptr;
             d.mid[1] = nullptr;
         }
-        (void)hipFree(d.off[dir]);
-        (void)hipFree(d.adj[dir]);
-        (void)hipFree(d.mid[dir]);
+        dev_free(d.off[dir]);
+        dev_free(d.adj[dir]);
+        dev_free(d.mid[dir]);
         d.off[dir] = nullptr;
         d.adj[dir] = nullptr;
         d.mid[dir] = nullptr;
     }
-    (void)hipFree(d.perm);
-    (void)hipFree(d.label);
+    dev_free(d.perm);
+    dev_free(d.label);
     d.perm = nullptr;
     d.label = nullptr;
 }
@@ -162,16 +171,16 @@ static void free_graph(DevState &d) {
 static void free_buffers(DevState &d) {
     (void)hipSetDevice(d.dev);
     for (int k = 0; k < GPM_MAXP; ++k) {
-        (void)hipFree(d.F[k]);
-        (void)hipFree(d.beg[k]);
-        (void)hipFree(d.cnt[k]);
-        (void)hipFree(d.pref[k]);
+        dev_free(d.F[k]);
+        dev_free(d.beg[k]);
+        dev_free(d.cnt[k]);
+        dev_free(d.pref[k]);
         d.F[k] = nullptr;
         d.beg[k] = d.cnt[k] = d.pref[k] = nullptr;
     }
-    (void)hipFree(d.scan_tmp);
-    (void)hipFree(d.emit);
-    (void)hipHostFree(d.emit_host);
+    dev_free(d.scan_tmp);
+    dev_free(d.emit);
+    host_free(d.emit_host);
     d.scan_tmp = nullptr;
     d.emit = nullptr;
     d.emit_host = nullptr;
@@ -188,10 +197,10 @@ extern "C" void gpm_hip_destroy(gpm_ctx *ctx) {
             (void)hipEventDestroy(ev.a);
             (void)hipEventDestroy(ev.b);
         }
-        (void)hipFree(d.ctr);
-        (void)hipHostFree(d.ctr_host);
-        (void)hipFree(d.i64_dev);
-        (void)hipHostFree(d.i64_host);
+        dev_free(d.ctr);
+        host_free(d.ctr_host);
+        dev_free(d.i64_dev);
+        host_free(d.i64_host);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
     delete ctx;
@@ -319,10 +328,10 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
     HIP_TRY(hipStreamSynchronize(s));
     if (hflags & 2u) {
         for (int dir = 0; dir < 2; ++dir) {
-            (void)hipFree(o_off[dir]);
-            (void)hipFree(o_adj[dir]);
+            dev_free(o_off[dir]);
+            dev_free(o_adj[dir]);
         }
-        (void)hipFree(flags);
+        dev_free(flags);
         return fail(GPM_EINVAL, "CSR arrays are inconsistent (offsets not monotone or ids out of range)");
     }
 
@@ -391,6 +400,7 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
 extern "C" int gpm_hip_upload_graph(gpm_ctx *ctx, int32_t n, const int64_t *out_off, const int32_t *out_adj,
                                     const int64_t *in_off, const int32_t *in_adj, const uint8_t *labels) {
     if (!ctx || n < 0 || !out_off || (!out_adj && out_off[n] > 0)) return fail(GPM_EINVAL, "bad graph arguments");
+    (void)hipGetLastError();
     if ((in_off == nullptr) != (in_adj == nullptr) && in_off && in_off[n] > 0)
         return fail(GPM_EINVAL, "in_off and in_adj must be given together");
     if (out_off[0] != 0 || out_off[n] < 0 || (in_off && in_off[n] != out_off[n]))
@@ -612,8 +622,8 @@ static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
         HIP_TRY(hipMalloc(&d.scan_tmp, d.scan_tmp_bytes));
     }
     if (want_emit > d.cap_emit) {
-        (void)hipFree(d.emit);
-        (void)hipHostFree(d.emit_host);
+        dev_free(d.emit);
+        host_free(d.emit_host);
         d.emit = nullptr;
         d.emit_host = nullptr;
         HIP_TRY(hipMalloc(&d.emit, (size_t)want_emit * (size_t)P * sizeof(int32_t)));
@@ -875,6 +885,7 @@ extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, v
     if (!ctx) return fail(GPM_EINVAL, "null context");
     if (!ctx->have_graph || !ctx->have_plan) return fail(GPM_ESTATE, "upload a graph and set a plan first");
     if (!count_only && !sink) return fail(GPM_EINVAL, "output mode needs a row sink");
+    (void)hipGetLastError();
     const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     ctx->stop = false;
     ctx->own_cursor = 0;
