@@ -67,3 +67,7 @@ double wallSeconds(void) {
     clock_gettime(CLOCK_MONOTONIC, &t);
     return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
+
+uint64_t claimChunk(volatile uint64_t *cursor) {
+    return __atomic_fetch_add((uint64_t *)cursor, 1, __ATOMIC_RELAXED);
+}

@@ -31,4 +31,11 @@ void sortIds(int32_t *a, int64_t n);
 
 double wallSeconds(void);
 
+/* Take the next root chunk from a cursor shared by every GPU worker of the
+ * node (threads of one process, or processes mapping the same memory):
+ * returns the chunk index, atomically incremented.  This replaces static
+ * vertex ownership (reference: assignNodesToProcesses, src/gpm-par.c:300-340)
+ * with work stealing. */
+uint64_t claimChunk(volatile uint64_t *cursor);
+
 #endif
