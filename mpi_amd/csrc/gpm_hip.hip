@@ -57,12 +57,14 @@ enum {  // slots of the per-device counter block (unsigned long long each)
     CTR_TAIL_MATCHES = 18,
     CTR_TAIL_BYTES = 19,
     CTR_EMIT = 20,
+    CTR_CLQ_CLASS0 = 24,  // [24, 29): roots per size class of the clique kernel
     CTR_COUNT = 32
 };
 
 struct EventPair {
     hipEvent_t a, b;
     int kind;  // 0 = tail kernel, 1 = extend kernel
+    int64_t rows;
 };
 
 struct DevState {
@@ -86,6 +88,12 @@ struct DevState {
     unsigned long long *ctr = nullptr;       // device counters
     unsigned long long *ctr_host = nullptr;  // pinned mirror for read-back
     int64_t *i64_dev = nullptr, *i64_host = nullptr;
+    // clique kernel: per-class root lists, global row scratch, spread result slots
+    int32_t *clq_lists = nullptr;
+    int64_t clq_stride = 0;
+    uint32_t *clq_scratch = nullptr;
+    int clq_scratch_blocks = 0;
+    unsigned long long *clq_slots = nullptr;  // [0,CLQ_SLOTS) matches, [CLQ_SLOTS,2*CLQ_SLOTS) bytes
     std::vector<EventPair> events;
     size_t events_used = 0;
     // results of the last search
@@ -111,6 +119,8 @@ struct gpm_ctx {
     PlanView pv{};
     TailInfo ti{};
     bool use_tail = true;
+    int clique_k = 0;  // K when the plan is a K-clique under a total ordering, else 0
+    bool use_clique = true;
     int64_t chunk_roots = 1 << 16;
     int64_t root_lo = 0, root_hi = 0;
     volatile uint64_t *shared_cursor = nullptr;
@@ -179,6 +189,12 @@ static void free_buffers(DevState &d) {
         d.beg[k] = d.cnt[k] = d.pref[k] = nullptr;
     }
     dev_free(d.scan_tmp);
+    dev_free(d.clq_lists);
+    dev_free(d.clq_scratch);
+    dev_free(d.clq_slots);
+    d.clq_lists = nullptr;
+    d.clq_scratch = nullptr;
+    d.clq_slots = nullptr;
     dev_free(d.emit);
     host_free(d.emit_host);
     d.scan_tmp = nullptr;
@@ -233,6 +249,7 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->chunk_roots = env_i64("GPM_CHUNK_ROOTS", 1 << 16);
     if (ctx->chunk_roots < 1) ctx->chunk_roots = 1;
     ctx->use_tail = env_i64("GPM_NO_TAIL", 0) == 0;
+    ctx->use_clique = env_i64("GPM_NO_CLIQUE", 0) == 0;
     *out = ctx;
     return GPM_OK;
 }
@@ -560,6 +577,22 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
         ti.reuse = ctx->info.simple && n_extra >= 1 && n_extra <= 2 && same_list_set(la, lb_rest) && same_bounds &&
                    same_filters && env_i64("GPM_NO_REUSE", 0) == 0;
     }
+    // K-clique under a total order: every level's operand lists are the lists of
+    // all earlier levels, each vertex is bounded below by its predecessor, and
+    // nothing but adjacency filters the candidates.
+    ctx->clique_k = 0;
+    if (P >= 3 && ctx->info.simple && ctx->info.symmetric) {
+        bool clique = true;
+        for (int k = 1; k < P && clique; ++k) {
+            const LevelPlan &lv = pv.lv[k];
+            unsigned have = 1u << lv.src_level;
+            for (int j = 0; j < lv.n_cons; ++j) have |= 1u << lv.cons_level[j];
+            clique = have == (1u << k) - 1 && lv.n_upper == 0 && lv.label < 0;
+            for (int t = 0; t < k; ++t) clique = clique && lt[t][k];
+        }
+        clique = clique && pv.lv[0].label < 0;
+        if (clique) ctx->clique_k = P;
+    }
     ctx->have_plan = true;
     return GPM_OK;
 }
@@ -621,6 +654,14 @@ static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
         d.scan_tmp_bytes = bytes ? bytes : 8;
         HIP_TRY(hipMalloc(&d.scan_tmp, d.scan_tmp_bytes));
     }
+    if (ctx->clique_k && !d.clq_lists) {
+        d.clq_stride = ctx->chunk_roots;
+        HIP_TRY(hipMalloc(&d.clq_lists, (size_t)5 * (size_t)d.clq_stride * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&d.clq_slots, 2 * CLQ_SLOTS * sizeof(unsigned long long)));
+        d.clq_scratch_blocks = (int)env_i64("GPM_CLIQUE_SCRATCH_BLOCKS", 1024);
+        HIP_TRY(hipMalloc(&d.clq_scratch,
+                          (size_t)d.clq_scratch_blocks * (size_t)CLQ_MAX_D * (CLQ_MAX_D / 32) * sizeof(uint32_t)));
+    }
     if (want_emit > d.cap_emit) {
         dev_free(d.emit);
         host_free(d.emit_host);
@@ -641,7 +682,7 @@ static int read_ctr(DevState &d, int slot, uint64_t *out) {
     return GPM_OK;
 }
 
-static int timed_begin(DevState &d, int kind) {
+static int timed_begin(DevState &d, int kind, int64_t rows = 0) {
     if (d.events_used == d.events.size()) {
         EventPair ev{};
         ev.kind = kind;
@@ -650,6 +691,7 @@ static int timed_begin(DevState &d, int kind) {
         d.events.push_back(ev);
     }
     d.events[d.events_used].kind = kind;
+    d.events[d.events_used].rows = rows;
     HIP_TRY(hipEventRecord(d.events[d.events_used].a, d.stream));
     return GPM_OK;
 }
@@ -665,6 +707,9 @@ static int collect_times(DevState &d) {
     for (size_t i = 0; i < d.events_used; ++i) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d.events[i].a, d.events[i].b));
+        if (getenv("GPM_TRACE"))
+            fprintf(stderr, "gpm trace: %s rows %lld ms %.3f\n", d.events[i].kind == 0 ? "tail" : "extend",
+                    (long long)d.events[i].rows, ms);
         if (d.events[i].kind == 0) {
             d.ms_tail += ms;
             d.tail_launches++;
@@ -730,7 +775,7 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
 
     if (a.count_only && ctx->use_tail && k == P - 2) {
         unsigned blocks = (unsigned)std::min<int64_t>((nrows + TAIL_WAVES - 1) / TAIL_WAVES, 16384);
-        int rc = timed_begin(d, 0);
+        int rc = timed_begin(d, 0, nrows);
         if (rc) return rc;
         k_tail<<<blocks, TAIL_WAVES * GPM_WAVE, 0, s>>>(d.gv, ctx->pv, ctx->ti, rows, nrows, d.ctr + CTR_TAIL_MATCHES,
                                                         d.ctr + CTR_TAIL_BYTES);
@@ -815,6 +860,94 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
     return GPM_OK;
 }
 
+// ---- clique fast path ------------------------------------------------------
+
+static size_t clq_lds_bytes(int dcap, bool rows_in_lds) {
+    size_t words = 3 * (size_t)dcap + (rows_in_lds ? (size_t)dcap * (size_t)(dcap / 32) : 0);
+    return words * sizeof(uint32_t);
+}
+
+template <int K>
+static int clique_launch(DevState &d, const uint64_t n[5]) {
+    hipStream_t s = d.stream;
+    unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + CLQ_SLOTS;
+    const int32_t *l = d.clq_lists;
+    const int64_t st = d.clq_stride;
+    int rc;
+    if (n[0]) {
+        if ((rc = timed_begin(d, 0, (int64_t)n[0]))) return rc;
+        k_clique<K, 64, true><<<(unsigned)n[0], 64, clq_lds_bytes(64, true), s>>>(d.gv, l, (int64_t)n[0], 64, nullptr,
+                                                                                  cnt, byt);
+        HIP_TRY(hipGetLastError());
+        if ((rc = timed_end(d))) return rc;
+    }
+    if (n[1]) {
+        if ((rc = timed_begin(d, 0, (int64_t)n[1]))) return rc;
+        k_clique<K, 256, true><<<(unsigned)n[1], 256, clq_lds_bytes(256, true), s>>>(d.gv, l + st, (int64_t)n[1], 256,
+                                                                                     nullptr, cnt, byt);
+        HIP_TRY(hipGetLastError());
+        if ((rc = timed_end(d))) return rc;
+    }
+    if (n[2]) {
+        const size_t lds = clq_lds_bytes(1024, true);
+        HIP_TRY(hipFuncSetAttribute((const void *)k_clique<K, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        if ((rc = timed_begin(d, 0, (int64_t)n[2]))) return rc;
+        k_clique<K, 512, true><<<(unsigned)n[2], 512, lds, s>>>(d.gv, l + 2 * st, (int64_t)n[2], 1024, nullptr, cnt,
+                                                                byt);
+        HIP_TRY(hipGetLastError());
+        if ((rc = timed_end(d))) return rc;
+    }
+    if (n[3]) {
+        unsigned blocks = (unsigned)std::min<uint64_t>(n[3], (uint64_t)d.clq_scratch_blocks);
+        if ((rc = timed_begin(d, 0, (int64_t)n[3]))) return rc;
+        k_clique<K, 256, false><<<blocks, 256, clq_lds_bytes(CLQ_MAX_D, false), s>>>(
+            d.gv, l + 3 * st, (int64_t)n[3], CLQ_MAX_D, d.clq_scratch, cnt, byt);
+        HIP_TRY(hipGetLastError());
+        if ((rc = timed_end(d))) return rc;
+    }
+    return GPM_OK;
+}
+
+static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows);
+
+// One chunk of roots through the bitmap kernel; roots whose N+ exceeds the
+// kernel's universe go through the generic level-by-level path instead.
+static int clique_chunk(const SearchArgs &a, DevState &d, int64_t lo, int64_t hi) {
+    gpm_ctx *ctx = a.ctx;
+    hipStream_t s = d.stream;
+    HIP_TRY(hipMemsetAsync(d.ctr + CTR_CLQ_CLASS0, 0, 5 * sizeof(unsigned long long), s));
+    const int max_d = (int)std::min<int64_t>(CLQ_MAX_D, std::max<int64_t>(0, env_i64("GPM_CLIQUE_MAX_D", CLQ_MAX_D)));
+    k_clique_bin<<<grid_for(hi - lo), 256, 0, s>>>(d.gv, ctx->clique_k, max_d, lo, hi, d.clq_lists, d.clq_stride,
+                                                   d.ctr + CTR_CLQ_CLASS0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(d.ctr_host + CTR_CLQ_CLASS0, d.ctr + CTR_CLQ_CLASS0, 5 * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    uint64_t n[5];
+    for (int c = 0; c < 5; ++c) n[c] = d.ctr_host[CTR_CLQ_CLASS0 + c];
+    d.rows_in[0] += n[0] + n[1] + n[2] + n[3];
+    int rc = GPM_OK;
+    switch (ctx->clique_k) {
+        case 3: rc = clique_launch<3>(d, n); break;
+        case 4: rc = clique_launch<4>(d, n); break;
+        case 5: rc = clique_launch<5>(d, n); break;
+        case 6: rc = clique_launch<6>(d, n); break;
+        case 7: rc = clique_launch<7>(d, n); break;
+        case 8: rc = clique_launch<8>(d, n); break;
+        case 9: rc = clique_launch<9>(d, n); break;
+        case 10: rc = clique_launch<10>(d, n); break;
+        default: return fail(GPM_ERUNTIME, "clique size %d not supported", ctx->clique_k);
+    }
+    if (rc) return rc;
+    if (n[4]) {
+        HIP_TRY(hipMemcpyAsync(d.F[0], d.clq_lists + 4 * d.clq_stride, (size_t)n[4] * sizeof(int32_t),
+                               hipMemcpyDeviceToDevice, s));
+        rc = expand(a, d, 1, (int64_t)n[4]);
+    }
+    return rc;
+}
+
 static uint64_t claim_chunk(gpm_ctx *ctx) {
     if (ctx->shared_cursor) return __atomic_fetch_add((uint64_t *)ctx->shared_cursor, 1, __ATOMIC_RELAXED);
     return ctx->own_cursor.fetch_add(1, std::memory_order_relaxed);
@@ -834,12 +967,23 @@ static int device_search(const SearchArgs &a, DevState &d) {
     d.events_used = 0;
     memset(d.rows_in, 0, sizeof d.rows_in);
     uint64_t p1_rows = 0;
+    const bool clique = a.count_only && ctx->clique_k >= 3 && ctx->use_clique;
+    if (clique) HIP_TRY(hipMemsetAsync(d.clq_slots, 0, 2 * CLQ_SLOTS * sizeof(unsigned long long), s));
     while (!ctx->stop) {
         const uint64_t c = claim_chunk(ctx);
         const int64_t lo = ctx->root_lo + (int64_t)c * ctx->chunk_roots;
         if (lo >= ctx->root_hi || (int64_t)c < 0) break;
         const int64_t hi = std::min(ctx->root_hi, lo + ctx->chunk_roots);
         d.chunks++;
+        if (clique) {
+            rc = clique_chunk(a, d, lo, hi);
+            if (rc) return rc;
+            if (d.events_used > 4096) {
+                HIP_TRY(hipStreamSynchronize(s));
+                if ((rc = collect_times(d))) return rc;
+            }
+            continue;
+        }
         HIP_TRY(hipMemsetAsync(d.ctr + CTR_LEVEL0, 0, sizeof(unsigned long long), s));
         k_filter_roots<<<grid_for(hi - lo), 256, 0, s>>>(d.gv, ctx->pv.lv[0], lo, hi, d.F[0], d.ctr + CTR_LEVEL0);
         HIP_TRY(hipGetLastError());
@@ -869,6 +1013,10 @@ static int device_search(const SearchArgs &a, DevState &d) {
             rc = collect_times(d);
             if (rc) return rc;
         }
+    }
+    if (clique) {
+        k_sum_slots<<<1, 64, 0, s>>>(d.clq_slots, CLQ_SLOTS, d.ctr + CTR_TAIL_MATCHES);
+        k_sum_slots<<<1, 64, 0, s>>>(d.clq_slots + CLQ_SLOTS, CLQ_SLOTS, d.ctr + CTR_TAIL_BYTES);
     }
     HIP_TRY(hipMemcpyAsync(d.ctr_host, d.ctr, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -355,3 +355,181 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
         if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
     }
 }
+
+// ---------------------------------------------------------------------------
+// Cliques: root-centric bitmap kernel
+// ---------------------------------------------------------------------------
+//
+// For a K-clique under the ordering bounds m0 < m1 < ... every vertex after
+// the root lies in U = N+(root), the part of the root's list above the root
+// (at most a few thousand ids after the degree renumbering).  One workgroup
+// takes one root, stages U in LDS, and builds the adjacency of the subgraph
+// induced on U as d rows of d bits: row i has bit j set iff U[j] is in
+// N+(U[i]) (so j > i).  That build is the neighbour-list intersection
+// N+(U[i]) ^ U, done once per (root, i) with coalesced reads of N+(U[i]) and
+// binary search in the LDS copy of U.  All deeper levels then run on the
+// bitmaps alone: a wave keeps row i in registers (lane l holds word l) and for
+// every set bit j ANDs in row j read from LDS, one 256-byte conflict-free
+// read per (i, j); the last level is a population count.
+
+#define CLQ_MAX_D 2048                 // 64 lanes x 32 bits
+#define CLQ_SLOTS 1024                 // result counters are spread over this many slots
+
+// Sort roots of a chunk into size classes by d = |N+(root)|; each class is a
+// compacted list (ballot + prefix popcount, one atomic per wave and class).
+//   class 0: K-1 <= d <= 64      class 1: d <= 256      class 2: d <= 1024
+//   class 3: d <= max_d <= CLQ_MAX_D (rows in global scratch)   class 4: larger (generic path)
+__global__ void k_clique_bin(GraphView g, int K, int max_d, int64_t lo, int64_t hi, int32_t *lists,
+                             int64_t list_stride, unsigned long long *counts) {
+    int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1;
+    int32_t v = 0;
+    if (i < hi) {
+        v = (int32_t)(g.n - 1 - i);
+        int64_t d = g.off[0][v + 1] - g.mid[0][v];
+        if (d >= K - 1) cls = d > max_d ? 4 : d <= 64 ? 0 : d <= 256 ? 1 : d <= 1024 ? 2 : 3;
+    }
+    int lane = lane_id();
+    for (int c = 0; c < 5; ++c) {
+        unsigned long long mask = __ballot(cls == c);
+        if (!mask) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(counts + c, (unsigned long long)__popcll(mask));
+        base = __shfl(base, 0, GPM_WAVE);
+        if (cls == c) lists[c * list_stride + base + __popcll(mask & ((1ull << lane) - 1))] = v;
+    }
+}
+
+// Row words are written with atomics (performed in L2); when the rows live in
+// global scratch they are read back with L1-bypassing loads, so a line left in
+// this CU's L1 by an earlier root can never be served stale.
+template <bool IN_LDS>
+__device__ __forceinline__ uint32_t clq_load(const uint32_t *p) {
+    if constexpr (IN_LDS) return *p;
+    else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Number of ways to complete a clique with R more vertices from the set C
+// (one 32-bit word per lane), given the bitmap rows.  Returns a per-lane
+// partial count; the caller sums over lanes.  `nodes` counts the internal
+// search nodes visited below this call (for the traffic model).
+template <int R, bool IN_LDS>
+__device__ __forceinline__ uint32_t clq_count(uint32_t C, const uint32_t *rows, int W, int lane, uint64_t &nodes) {
+    if constexpr (R == 1) {
+        return __popc(C);
+    } else {
+        uint32_t acc = 0;
+        for (int w = 0; w < W; ++w) {
+            uint32_t word = __builtin_amdgcn_readlane(C, w);  // same word for the whole wave
+            while (word) {
+                int j = (w << 5) + __builtin_ctz(word);
+                word &= word - 1;
+                uint32_t rj = lane < W ? clq_load<IN_LDS>(rows + (int64_t)j * W + lane) : 0u;
+                if constexpr (R > 2) nodes += 1;
+                acc += clq_count<R - 1, IN_LDS>(C & rj, rows, W, lane, nodes);
+            }
+        }
+        return acc;
+    }
+}
+
+// One workgroup (BLOCK threads) per root.  Dynamic LDS layout, in 32-bit
+// words: U[dcap] | Dp[dcap] | col[dcap] | rows[dcap * wcap] (rows only when
+// IN_LDS; otherwise rows live in this workgroup's slab of `scratch`).
+template <int K, int BLOCK, bool IN_LDS>
+__global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
+                                                  uint32_t *scratch, unsigned long long *n_matches,
+                                                  unsigned long long *alg_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr int NW = BLOCK / GPM_WAVE;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
+    int32_t *U = (int32_t *)smem;
+    uint32_t *Dp = smem + dcap;
+    uint32_t *col = smem + 2 * dcap;
+    uint32_t *rows = IN_LDS ? smem + 3 * dcap : scratch + (size_t)blockIdx.x * ((size_t)CLQ_MAX_D * (CLQ_MAX_D / 32));
+    const int64_t *off = g.off[0], *mid = g.mid[0];
+    const int32_t *adj = g.adj[0];
+    uint64_t total = 0, bytes = 0;
+
+    for (int64_t ri = blockIdx.x; ri < nroots; ri += gridDim.x) {
+        const int32_t u = roots[ri];
+        const int64_t ub = mid[u];
+        const int d = (int)(off[u + 1] - ub);
+        const int W = (d + 31) >> 5;
+        for (int i = tid; i < d; i += BLOCK) {
+            int32_t v = adj[ub + i];
+            U[i] = v;
+            Dp[i] = (uint32_t)(off[v + 1] - mid[v]);
+            col[i] = 0;
+        }
+        for (int i = tid; i < d * W; i += BLOCK) rows[i] = 0;
+        __syncthreads();
+
+        // build the rows: N+(U[i]) ^ U, walking whichever side is shorter
+        for (int i = wave; i < d - 1; i += NW) {
+            const int32_t v = U[i];
+            const int64_t vb = mid[v], ve = off[v + 1];
+            uint32_t *row = rows + (int64_t)i * W;
+            if (ve - vb <= (int64_t)(d - 1 - i) * 2) {
+                for (int64_t p = vb + lane; p < ve; p += GPM_WAVE) {
+                    int32_t c = adj[p];
+                    int j = lower_bound_s(U, i + 1, d, c);
+                    if (j < d && U[j] == c) {
+                        atomicOr(row + (j >> 5), 1u << (j & 31));
+                        atomicAdd(col + j, 1u);
+                    }
+                }
+            } else {
+                for (int j = i + 1 + lane; j < d; j += GPM_WAVE) {
+                    if (contains_g(adj, vb, ve, U[j])) {
+                        atomicOr(row + (j >> 5), 1u << (j & 31));
+                        atomicAdd(col + j, 1u);
+                    }
+                }
+            }
+        }
+        if (!IN_LDS) __threadfence_block();
+        __syncthreads();
+
+        // count on the bitmaps
+        uint64_t nodes = 0;
+        for (int i = wave; i < d; i += NW) {
+            uint32_t r = lane < W ? clq_load<IN_LDS>(rows + (int64_t)i * W + lane) : 0u;
+            total += clq_count<K - 2, IN_LDS>(r, rows, W, lane, nodes);
+        }
+
+        // merge-model bytes of the levels fused here (one thread per local vertex):
+        //   root -> level 1        : 4*1 + 4*d
+        //   (root,i) -> level 2    : 4*2 + 4*(d + Dp[i])                       for every i
+        //   (root,i,j) -> level 3  : 4*3 + 4*(d + Dp[i] + Dp[j])              for every arc i->j of the rows
+        // (deeper internal nodes, K > 4, are counted as 4*(t+1) + 4*d each: a lower bound)
+        if (K >= 3) {
+            uint64_t b = 0;
+            for (int i = tid; i < d; i += BLOCK) {
+                b += 8ull + 4ull * ((uint64_t)d + Dp[i]);
+                if (K >= 4) {
+                    uint32_t out_i = 0;  // arcs leaving i
+                    for (int w = 0; w < W; ++w) out_i += __popc(clq_load<IN_LDS>(rows + (int64_t)i * W + w));
+                    b += (uint64_t)out_i * (12ull + 4ull * ((uint64_t)d + Dp[i])) + 4ull * (uint64_t)col[i] * Dp[i];
+                }
+            }
+            if (tid == 0) b += 4ull + 4ull * (uint64_t)d;
+            if (K >= 5 && lane == 0) b += nodes * (16ull + 4ull * (uint64_t)d);
+            bytes += b;
+        }
+        __syncthreads();
+    }
+    total = wave_sum_u64(total);
+    bytes = wave_sum_u64(bytes);
+    if (lane == 0) {
+        if (total) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)total);
+        if (bytes) atomicAdd(alg_bytes + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)bytes);
+    }
+}
+
+__global__ void k_sum_slots(const unsigned long long *slots, int n, unsigned long long *out) {
+    unsigned long long s = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += slots[i];
+    s = wave_sum_u64(s);
+    if (lane_id() == 0 && s) atomicAdd(out, s);
+}

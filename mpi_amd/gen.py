@@ -171,6 +171,7 @@ PATTERNS = {
     "tree5": (5, _both([(1, 2), (1, 3), (3, 4), (3, 5)])),
     "tree5_dir": (5, [(1, 2), (1, 3), (3, 4), (5, 3)]),
     "clique5": (5, _both([(a, b) for a in range(1, 6) for b in range(a + 1, 6)])),
+    "clique6": (6, _both([(a, b) for a in range(1, 7) for b in range(a + 1, 7)])),
     "house": (5, _both([(1, 2), (2, 3), (3, 4), (4, 1), (1, 5), (2, 5)])),
     # K6 minus a perfect matching (the octahedron): 12 undirected edges
     "k6_minus_pm": (6, _both([(a, b) for a in range(1, 7) for b in range(a + 1, 7)

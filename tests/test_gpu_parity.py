@@ -108,6 +108,9 @@ VARIANTS = [
     {"symbreak": False, "env": {"GPM_NO_TAIL": "1"}},
     {"symbreak": True, "env": {"GPM_NO_REUSE": "1"}},
     {"symbreak": True, "env": {"GPM_ARENA_ROWS": "4096", "GPM_CHUNK_ROOTS": "64", "GPM_EMIT_ROWS": "1000"}},
+    {"symbreak": True, "env": {"GPM_NO_CLIQUE": "1"}},
+    {"symbreak": True, "env": {"GPM_CLIQUE_MAX_D": "6"}},
+    {"symbreak": True, "env": {"GPM_NO_CLIQUE": "1", "GPM_NO_REUSE": "1"}},
 ]
 VAR_SPECS = [g for g in GOLDEN if g["name"] in (
     "rand9_sym_clique4", "rand9_sym_cycle4", "rand9_dir_tree5_dir", "rand40_dir_rev4", "rand40_dir_k4_dag",
@@ -183,6 +186,48 @@ def test_mid_size_properties(pname):
     assert counts[0] == counts[1]
     if want is not None:
         assert counts[0] == want
+
+
+def complete_graph(n):
+    a = np.repeat(np.arange(n), n)
+    b = np.tile(np.arange(n), n)
+    keep = a != b
+    return a[keep], b[keep]
+
+
+@pytest.mark.parametrize("n,pname", [(70, "clique4"), (70, "clique6"), (300, "triangle"), (300, "clique4"),
+                                     (300, "clique5"), (1100, "clique4"), (1300, "triangle")])
+def test_cliques_in_complete_graphs_closed_form(n, pname):
+    """K_n holds n!/(n-k)! embeddings of the k-clique; n = 70 / 300 / 1100+ put the roots in the
+    one-wave, LDS-row and global-row classes of the bitmap kernel."""
+    s, d = complete_graph(n)
+    k = gen.PATTERNS[pname][0]
+    want = 1
+    for i in range(k):
+        want *= n - i
+    m = binding.Matcher(1)
+    upload(m, n, s, d)
+    m.set_pattern(gen.PATTERNS[pname])
+    assert m.findMatches(count_only=True) == want
+    m.close()
+
+
+def test_clique_kernel_equals_generic_path(monkeypatch):
+    """Bitmap kernel vs level-by-level path on R-MAT scale 13, K = 3..6, incl. a mixed split of the roots."""
+    n, s, d = util.build_graph({"graph": "rmat", "scale": 13, "ef": 8, "seed": 3})
+    for pname in ("triangle", "clique4", "clique5", "clique6"):
+        counts = []
+        for env in ({}, {"GPM_NO_CLIQUE": "1"}, {"GPM_CLIQUE_MAX_D": "40"}):
+            for k in ("GPM_NO_CLIQUE", "GPM_CLIQUE_MAX_D"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            m = binding.Matcher(1)
+            upload(m, n, s, d)
+            m.set_pattern(gen.PATTERNS[pname])
+            counts.append(m.findMatches(count_only=True))
+            m.close()
+        assert counts[0] == counts[1] == counts[2], (pname, counts)
 
 
 def test_bad_arguments_are_rejected():
