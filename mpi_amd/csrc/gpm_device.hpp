@@ -17,7 +17,19 @@ struct GraphView {
     const int32_t *adj[2];
     const int64_t *mid[2];  // first position in v's list with id > v
     const uint8_t *label;   // by internal id, or nullptr
+    // Hub matrix: the arcs among the hub_rows highest-degree vertices (ids >=
+    // hub_base) as a dense bitmap, row v - hub_base, bit c - hub_base set iff
+    // v -> c.  Membership tests between two hubs are one load instead of a
+    // binary search in a long list.
+    int32_t hub_base;       // n when there is no hub matrix
+    int32_t hub_wpr;        // 32-bit words per row
+    const uint32_t *hub;
 };
+
+__device__ __forceinline__ bool hub_arc(const GraphView &g, int32_t from, int32_t to) {
+    uint32_t c = (uint32_t)(to - g.hub_base);
+    return (g.hub[(size_t)(from - g.hub_base) * (size_t)g.hub_wpr + (c >> 5)] >> (c & 31)) & 1u;
+}
 
 enum { PART_FULL = 0, PART_ABOVE = 1, PART_BELOW = 2 };
 
@@ -64,11 +76,22 @@ __device__ __forceinline__ int lower_bound_s(const int32_t *a, int b, int e, int
     return b;
 }
 
+// Is c in N_dir(v)?  (dir 0: arc v -> c, dir 1: arc c -> v.)  `part` only
+// narrows the search; the caller guarantees c lies in that part.
+__device__ __forceinline__ bool in_list(const GraphView &g, int dir, int part, int32_t v, int32_t c);
+
 __device__ __forceinline__ void list_range(const GraphView &g, int dir, int part, int32_t v, int64_t &b, int64_t &e) {
     b = g.off[dir][v];
     e = g.off[dir][v + 1];
     if (part == PART_ABOVE) b = g.mid[dir][v];
     else if (part == PART_BELOW) e = g.mid[dir][v];
+}
+
+__device__ __forceinline__ bool in_list(const GraphView &g, int dir, int part, int32_t v, int32_t c) {
+    if (v >= g.hub_base && c >= g.hub_base) return dir == 0 ? hub_arc(g, v, c) : hub_arc(g, c, v);
+    int64_t b, e;
+    list_range(g, dir, part, v, b, e);
+    return contains_g(g.adj[dir], b, e, c);
 }
 
 // Candidate range of one level for the partial match m: the source list cut
@@ -107,11 +130,9 @@ __device__ __forceinline__ bool accept(const GraphView &g, const LevelPlan &lv, 
         if (m[t] == c) return false;
     if (!vertex_ok(g, lv, c)) return false;
     for (int j = 0; j < lv.n_cons; ++j) {
-        int64_t b, e;
-        if (j == skip_cons) list_range(g, lv.src_dir, lv.src_part, m[lv.src_level], b, e);
-        else list_range(g, lv.cons_dir[j], lv.cons_part[j], m[lv.cons_level[j]], b, e);
-        const int32_t *a = g.adj[j == skip_cons ? lv.src_dir : lv.cons_dir[j]];
-        if (!contains_g(a, b, e, c)) return false;
+        bool in = j == skip_cons ? in_list(g, lv.src_dir, lv.src_part, m[lv.src_level], c)
+                                 : in_list(g, lv.cons_dir[j], lv.cons_part[j], m[lv.cons_level[j]], c);
+        if (!in) return false;
     }
     return true;
 }

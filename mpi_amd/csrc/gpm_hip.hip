@@ -77,6 +77,7 @@ struct DevState {
     int32_t *adj[2] = {nullptr, nullptr};
     int32_t *perm = nullptr;
     uint8_t *label = nullptr;
+    uint32_t *hub = nullptr;
     GraphView gv{};
     // search buffers
     int64_t cap_rows = 0, cap_emit = 0;
@@ -174,8 +175,10 @@ static void free_graph(DevState &d) {
     }
     dev_free(d.perm);
     dev_free(d.label);
+    dev_free(d.hub);
     d.perm = nullptr;
     d.label = nullptr;
+    d.hub = nullptr;
 }
 
 static void free_buffers(DevState &d) {
@@ -411,6 +414,24 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
         d.gv.mid[dir] = d.mid[dir];
     }
     d.gv.label = d.label;
+
+    // hub matrix over the highest-degree vertices (the last ids after renumbering)
+    int64_t hub_rows = std::min<int64_t>(env_i64("GPM_HUB_ROWS", (int64_t)1 << 18), ((int64_t)n + 63) / 64 * 64);
+    hub_rows = std::max<int64_t>(0, hub_rows / 64 * 64);
+    d.gv.hub_base = n;
+    d.gv.hub_wpr = 0;
+    d.gv.hub = nullptr;
+    if (hub_rows > 0 && n > 0) {
+        const size_t bytes = (size_t)hub_rows * (size_t)(hub_rows / 32) * sizeof(uint32_t);
+        HIP_TRY(hipMalloc(&d.hub, bytes));
+        HIP_TRY(hipMemsetAsync(d.hub, 0, bytes, s));
+        d.gv.hub_base = (int32_t)std::max<int64_t>(0, (int64_t)n - hub_rows);
+        d.gv.hub_wpr = (int32_t)(hub_rows / 32);
+        d.gv.hub = d.hub;
+        k_hub_fill<<<(unsigned)(n - d.gv.hub_base), 256, 0, s>>>(d.gv, d.hub);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     return GPM_OK;
 }
 
@@ -862,8 +883,12 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
 
 // ---- clique fast path ------------------------------------------------------
 
-static size_t clq_lds_bytes(int dcap, bool rows_in_lds) {
-    size_t words = 3 * (size_t)dcap + (rows_in_lds ? (size_t)dcap * (size_t)(dcap / 32) : 0);
+// Dynamic LDS of k_clique<K, BLOCK, rows_in_lds>; must mirror the kernel's layout.
+static size_t clq_lds_bytes(int K, int block, int dcap, bool rows_in_lds) {
+    const size_t wcap = dcap / 32 < 4 ? 4 : dcap / 32;
+    const size_t depths = K > 3 ? K - 3 : 1;
+    size_t words = 2 * (size_t)dcap + (size_t)(block / GPM_WAVE) * ((size_t)dcap / 2 + depths * wcap) +
+                   (rows_in_lds ? (size_t)dcap * wcap : 0);
     return words * sizeof(uint32_t);
 }
 
@@ -876,20 +901,20 @@ static int clique_launch(DevState &d, const uint64_t n[5]) {
     int rc;
     if (n[0]) {
         if ((rc = timed_begin(d, 0, (int64_t)n[0]))) return rc;
-        k_clique<K, 64, true><<<(unsigned)n[0], 64, clq_lds_bytes(64, true), s>>>(d.gv, l, (int64_t)n[0], 64, nullptr,
+        k_clique<K, 64, true><<<(unsigned)n[0], 64, clq_lds_bytes(K, 64, 64, true), s>>>(d.gv, l, (int64_t)n[0], 64, nullptr,
                                                                                   cnt, byt);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d))) return rc;
     }
     if (n[1]) {
         if ((rc = timed_begin(d, 0, (int64_t)n[1]))) return rc;
-        k_clique<K, 256, true><<<(unsigned)n[1], 256, clq_lds_bytes(256, true), s>>>(d.gv, l + st, (int64_t)n[1], 256,
+        k_clique<K, 256, true><<<(unsigned)n[1], 256, clq_lds_bytes(K, 256, 256, true), s>>>(d.gv, l + st, (int64_t)n[1], 256,
                                                                                      nullptr, cnt, byt);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d))) return rc;
     }
     if (n[2]) {
-        const size_t lds = clq_lds_bytes(1024, true);
+        const size_t lds = clq_lds_bytes(K, 512, 1024, true);
         HIP_TRY(hipFuncSetAttribute((const void *)k_clique<K, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
         if ((rc = timed_begin(d, 0, (int64_t)n[2]))) return rc;
@@ -901,7 +926,7 @@ static int clique_launch(DevState &d, const uint64_t n[5]) {
     if (n[3]) {
         unsigned blocks = (unsigned)std::min<uint64_t>(n[3], (uint64_t)d.clq_scratch_blocks);
         if ((rc = timed_begin(d, 0, (int64_t)n[3]))) return rc;
-        k_clique<K, 256, false><<<blocks, 256, clq_lds_bytes(CLQ_MAX_D, false), s>>>(
+        k_clique<K, 256, false><<<blocks, 256, clq_lds_bytes(K, 256, CLQ_MAX_D, false), s>>>(
             d.gv, l + 3 * st, (int64_t)n[3], CLQ_MAX_D, d.clq_scratch, cnt, byt);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d))) return rc;

@@ -240,8 +240,8 @@ __device__ __forceinline__ uint32_t tail_reuse_count(const GraphView &g, const T
     if ((int64_t)(se - sb) <= e0 - b0) {
         for (int i = sb + lane; i < se; i += GPM_WAVE) {
             int32_t c = staged[i];
-            bool ok = c != a && contains_g(adj0, b0, e0, c);
-            if (ok && adj1) ok = contains_g(adj1, b1, e1, c);
+            bool ok = c != a && in_list(g, ti.extra_dir[0], ti.extra_part[0], a, c);
+            if (ok && adj1) ok = in_list(g, ti.extra_dir[1], ti.extra_part[1], a, c);
             cnt += ok;
         }
     } else {
@@ -357,22 +357,41 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
 }
 
 // ---------------------------------------------------------------------------
+// Graph preparation: hub matrix
+// ---------------------------------------------------------------------------
+
+// One workgroup per hub vertex: set the bits of its arcs to other hubs.
+__global__ void k_hub_fill(GraphView g, uint32_t *bits) {
+    const int32_t v = g.hub_base + blockIdx.x;
+    if (v >= g.n) return;
+    const int64_t e = g.off[0][v + 1];
+    int64_t b = lower_bound_g(g.adj[0], g.off[0][v], e, g.hub_base);
+    uint32_t *row = bits + (size_t)blockIdx.x * (size_t)g.hub_wpr;
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+        uint32_t c = (uint32_t)(g.adj[0][i] - g.hub_base);
+        atomicOr(row + (c >> 5), 1u << (c & 31));
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Cliques: root-centric bitmap kernel
 // ---------------------------------------------------------------------------
 //
 // For a K-clique under the ordering bounds m0 < m1 < ... every vertex after
 // the root lies in U = N+(root), the part of the root's list above the root
 // (at most a few thousand ids after the degree renumbering).  One workgroup
-// takes one root, stages U in LDS, and builds the adjacency of the subgraph
+// takes one root, stages U in LDS and builds the adjacency of the subgraph
 // induced on U as d rows of d bits: row i has bit j set iff U[j] is in
-// N+(U[i]) (so j > i).  That build is the neighbour-list intersection
-// N+(U[i]) ^ U, done once per (root, i) with coalesced reads of N+(U[i]) and
-// binary search in the LDS copy of U.  All deeper levels then run on the
-// bitmaps alone: a wave keeps row i in registers (lane l holds word l) and for
-// every set bit j ANDs in row j read from LDS, one 256-byte conflict-free
-// read per (i, j); the last level is a population count.
+// N+(U[i]) (so j > i).  A row is N+(U[i]) ^ U: for a hub U[i] it is gathered
+// from the hub matrix, 64 bits per ballot; otherwise N+(U[i]) is streamed with
+// coalesced reads and looked up in the LDS copy of U.  All deeper levels run
+// on the bitmaps alone.  The last two levels are fused: the set bits j of the
+// current candidate set C are expanded into a list, and groups of lanes each
+// take one j, read row j from LDS 16 bytes per lane, AND it with C and add the
+// population count -- |C ^ row_j| for 64/L values of j per wave instruction,
+// where L = lanes per row.
 
-#define CLQ_MAX_D 2048                 // 64 lanes x 32 bits
+#define CLQ_MAX_D 2048                 // largest universe (bits per row)
 #define CLQ_SLOTS 1024                 // result counters are spread over this many slots
 
 // Sort roots of a chunk into size classes by d = |N+(root)|; each class is a
@@ -400,53 +419,114 @@ __global__ void k_clique_bin(GraphView g, int K, int max_d, int64_t lo, int64_t 
     }
 }
 
-// Row words are written with atomics (performed in L2); when the rows live in
-// global scratch they are read back with L1-bypassing loads, so a line left in
-// this CU's L1 by an earlier root can never be served stale.
-template <bool IN_LDS>
-__device__ __forceinline__ uint32_t clq_load(const uint32_t *p) {
-    if constexpr (IN_LDS) return *p;
-    else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+__device__ __forceinline__ u32x4 and4(u32x4 a, u32x4 b) { return {a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w}; }
+__device__ __forceinline__ uint32_t popc4(u32x4 a) { return __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w); }
+__device__ __forceinline__ u32x4 load4(const uint32_t *p) {
+    uint4 v = *reinterpret_cast<const uint4 *>(p);
+    return {v.x, v.y, v.z, v.w};
 }
 
-// Number of ways to complete a clique with R more vertices from the set C
-// (one 32-bit word per lane), given the bitmap rows.  Returns a per-lane
-// partial count; the caller sums over lanes.  `nodes` counts the internal
-// search nodes visited below this call (for the traffic model).
-template <int R, bool IN_LDS>
-__device__ __forceinline__ uint32_t clq_count(uint32_t C, const uint32_t *rows, int W, int lane, uint64_t &nodes) {
+// Geometry of one root's bitmaps.
+struct ClqGeom {
+    int d;    // universe size
+    int Wp;   // 32-bit words per row, a multiple of 4 (rows are 16-byte aligned)
+    int L;    // lanes that hold one row, 4 words each: power of two, 1..16
+    int lg;   // log2(L)
+};
+
+// Per-wave scratch in LDS.
+struct ClqWave {
+    uint16_t *J;        // expanded list of set-bit positions
+    uint32_t *cbuf;     // one candidate set per nesting depth, Wp words each
+};
+
+// Expand the set bits of the Wp-word bitmap at `words` (LDS) into J; returns
+// how many.  Lane l looks at bit l&31 of word 2t + (l>>5); one ballot places
+// 64 bits at a time.
+__device__ __forceinline__ int clq_expand(const uint32_t *words, int Wp, uint16_t *J, int lane) {
+    int cnt = 0;
+    for (int w0 = 0; w0 < Wp; w0 += 2) {
+        uint32_t word = words[w0 + (lane >> 5)];
+        bool bit = (word >> (lane & 31)) & 1u;
+        unsigned long long mask = __ballot(bit);
+        if (bit) J[cnt + __popcll(mask & ((1ull << lane) - 1))] = (uint16_t)((w0 << 5) + lane);
+        cnt += __popcll(mask);
+    }
+    return cnt;
+}
+
+// Ways to complete a clique with R more vertices out of the candidate set C.
+// C is held 4 words per lane by lanes 0..L-1 and replicated in every group of
+// L lanes.  Returns a per-lane partial sum (each completed clique is counted
+// in exactly one lane).  `depth` indexes the per-depth LDS copies of C.
+template <int R>
+__device__ __forceinline__ uint64_t clq_count(u32x4 C, const uint32_t *c_words, const uint32_t *rows,
+                                              const ClqGeom &q, const ClqWave &ws, int depth, int lane,
+                                              uint64_t &nodes) {
+    const int sub = lane & (q.L - 1);
+    const bool lane_ok = 4 * sub < q.Wp;  // L is Wp/4 rounded up to a power of two
     if constexpr (R == 1) {
-        return __popc(C);
-    } else {
+        return lane < q.L ? popc4(C) : 0u;
+    } else if constexpr (R == 2) {
+        // fused last two levels: |C ^ row_j| for every j in C, 64/L at a time
+        wave_lds_sync();
+        const int cnt = clq_expand(c_words, q.Wp, ws.J, lane);
+        wave_lds_sync();
+        if (depth >= 0) nodes += (uint64_t)cnt;
         uint32_t acc = 0;
-        for (int w = 0; w < W; ++w) {
-            uint32_t word = __builtin_amdgcn_readlane(C, w);  // same word for the whole wave
+        const int G = GPM_WAVE >> q.lg;
+        if (lane_ok) {
+            for (int t = lane >> q.lg; t < cnt; t += G) {
+                int j = ws.J[t];
+                acc += popc4(and4(C, load4(rows + (size_t)j * q.Wp + 4 * sub)));
+            }
+        }
+        return acc;
+    } else {
+        uint64_t acc = 0;
+        uint32_t *next = ws.cbuf + (size_t)(depth + 1) * q.Wp;
+        for (int w = 0; w < q.Wp; ++w) {
+            uint32_t word = __builtin_amdgcn_readfirstlane(c_words[w]);
             while (word) {
                 int j = (w << 5) + __builtin_ctz(word);
                 word &= word - 1;
-                uint32_t rj = lane < W ? clq_load<IN_LDS>(rows + (int64_t)j * W + lane) : 0u;
-                if constexpr (R > 2) nodes += 1;
-                acc += clq_count<R - 1, IN_LDS>(C & rj, rows, W, lane, nodes);
+                u32x4 C2 = {0u, 0u, 0u, 0u};
+                if (lane_ok) C2 = and4(C, load4(rows + (size_t)j * q.Wp + 4 * sub));
+                wave_lds_sync();
+                if (lane < q.L && lane_ok)
+                    *reinterpret_cast<uint4 *>(next + 4 * sub) = make_uint4(C2.x, C2.y, C2.z, C2.w);
+                wave_lds_sync();
+                if (depth >= 0) nodes += 1;
+                acc += clq_count<R - 1>(C2, next, rows, q, ws, depth + 1, lane, nodes);
             }
         }
         return acc;
     }
 }
 
-// One workgroup (BLOCK threads) per root.  Dynamic LDS layout, in 32-bit
-// words: U[dcap] | Dp[dcap] | col[dcap] | rows[dcap * wcap] (rows only when
-// IN_LDS; otherwise rows live in this workgroup's slab of `scratch`).
+// One workgroup (BLOCK threads) per root.  Dynamic LDS layout, 32-bit words:
+//   U[dcap] | Dp[dcap] | per wave: J[dcap/2] cbuf[(K-2) * wcap] | rows[dcap * wcap] (IN_LDS only)
+// With !IN_LDS the rows live in this workgroup's slab of `scratch`.
 template <int K, int BLOCK, bool IN_LDS>
 __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
                                                   uint32_t *scratch, unsigned long long *n_matches,
                                                   unsigned long long *alg_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int NW = BLOCK / GPM_WAVE;
+    constexpr int DEPTHS = K > 3 ? K - 3 : 1;  // nested candidate sets kept in LDS
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
+    const int wcap = dcap / 32 < 4 ? 4 : dcap / 32;
     int32_t *U = (int32_t *)smem;
     uint32_t *Dp = smem + dcap;
-    uint32_t *col = smem + 2 * dcap;
-    uint32_t *rows = IN_LDS ? smem + 3 * dcap : scratch + (size_t)blockIdx.x * ((size_t)CLQ_MAX_D * (CLQ_MAX_D / 32));
+    uint32_t *wave_base = smem + 2 * dcap + (size_t)wave * (size_t)(dcap / 2 + DEPTHS * wcap);
+    ClqWave ws;
+    ws.J = (uint16_t *)wave_base;
+    ws.cbuf = wave_base + dcap / 2;
+    uint32_t *rows = IN_LDS ? smem + 2 * dcap + (size_t)NW * (size_t)(dcap / 2 + DEPTHS * wcap)
+                            : scratch + (size_t)blockIdx.x * ((size_t)CLQ_MAX_D * (CLQ_MAX_D / 32));
     const int64_t *off = g.off[0], *mid = g.mid[0];
     const int32_t *adj = g.adj[0];
     uint64_t total = 0, bytes = 0;
@@ -454,69 +534,82 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
     for (int64_t ri = blockIdx.x; ri < nroots; ri += gridDim.x) {
         const int32_t u = roots[ri];
         const int64_t ub = mid[u];
-        const int d = (int)(off[u + 1] - ub);
-        const int W = (d + 31) >> 5;
+        ClqGeom q;
+        q.d = (int)(off[u + 1] - ub);
+        q.Wp = (((q.d + 31) >> 5) + 3) & ~3;
+        q.lg = q.Wp <= 4 ? 0 : q.Wp <= 8 ? 1 : q.Wp <= 16 ? 2 : q.Wp <= 32 ? 3 : 4;
+        q.L = 1 << q.lg;
+        const int d = q.d, Wp = q.Wp;
         for (int i = tid; i < d; i += BLOCK) {
             int32_t v = adj[ub + i];
             U[i] = v;
             Dp[i] = (uint32_t)(off[v + 1] - mid[v]);
-            col[i] = 0;
         }
-        for (int i = tid; i < d * W; i += BLOCK) rows[i] = 0;
         __syncthreads();
 
-        // build the rows: N+(U[i]) ^ U, walking whichever side is shorter
-        for (int i = wave; i < d - 1; i += NW) {
+        // ---- build the rows: row i = N+(U[i]) ^ U, as bits over positions in U
+        uint64_t arcs_bytes = 0;  // per lane: sum over its arcs i->j of 12 + 4*(d + Dp[i] + Dp[j])
+        for (int i = wave; i < d; i += NW) {
             const int32_t v = U[i];
-            const int64_t vb = mid[v], ve = off[v + 1];
-            uint32_t *row = rows + (int64_t)i * W;
-            if (ve - vb <= (int64_t)(d - 1 - i) * 2) {
+            uint32_t *row = rows + (size_t)i * Wp;
+            const uint64_t per_arc = 12ull + 4ull * ((uint64_t)d + Dp[i]);
+            if (v >= g.hub_base) {
+                const uint32_t *hrow = g.hub + (size_t)(v - g.hub_base) * (size_t)g.hub_wpr;
+                for (int j0 = 0; j0 < Wp * 32; j0 += GPM_WAVE) {
+                    const int j = j0 + lane;
+                    bool bit = false;
+                    if (j0 + GPM_WAVE > i + 1 && j > i && j < d) {
+                        uint32_t c = (uint32_t)(U[j] - g.hub_base);
+                        bit = (hrow[c >> 5] >> (c & 31)) & 1u;
+                    }
+                    unsigned long long mask = __ballot(bit);
+                    if (bit) arcs_bytes += per_arc + 4ull * Dp[j];
+                    if (lane == 0) {
+                        row[j0 >> 5] = (uint32_t)mask;
+                        row[(j0 >> 5) + 1] = (uint32_t)(mask >> 32);
+                    }
+                }
+            } else {
+                for (int w = lane; w < Wp; w += GPM_WAVE) row[w] = 0;
+                if (!IN_LDS) __threadfence_block();
+                wave_lds_sync();
+                const int64_t vb = mid[v], ve = off[v + 1];
                 for (int64_t p = vb + lane; p < ve; p += GPM_WAVE) {
                     int32_t c = adj[p];
                     int j = lower_bound_s(U, i + 1, d, c);
                     if (j < d && U[j] == c) {
                         atomicOr(row + (j >> 5), 1u << (j & 31));
-                        atomicAdd(col + j, 1u);
-                    }
-                }
-            } else {
-                for (int j = i + 1 + lane; j < d; j += GPM_WAVE) {
-                    if (contains_g(adj, vb, ve, U[j])) {
-                        atomicOr(row + (j >> 5), 1u << (j & 31));
-                        atomicAdd(col + j, 1u);
+                        arcs_bytes += per_arc + 4ull * Dp[j];
                     }
                 }
             }
         }
-        if (!IN_LDS) __threadfence_block();
+        if (!IN_LDS) {  // rows were written with stores and L2 atomics: drop this CU's stale L1 lines
+            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         __syncthreads();
 
-        // count on the bitmaps
+        // ---- count on the bitmaps
         uint64_t nodes = 0;
+        const int sub = lane & (q.L - 1);
         for (int i = wave; i < d; i += NW) {
-            uint32_t r = lane < W ? clq_load<IN_LDS>(rows + (int64_t)i * W + lane) : 0u;
-            total += clq_count<K - 2, IN_LDS>(r, rows, W, lane, nodes);
+            const uint32_t *row = rows + (size_t)i * Wp;
+            u32x4 C = {0u, 0u, 0u, 0u};
+            if (4 * sub < Wp) C = load4(row + 4 * sub);
+            total += clq_count<K - 2>(C, row, rows, q, ws, -1, lane, nodes);
         }
 
-        // merge-model bytes of the levels fused here (one thread per local vertex):
+        // merge-model bytes of the levels fused here:
         //   root -> level 1        : 4*1 + 4*d
-        //   (root,i) -> level 2    : 4*2 + 4*(d + Dp[i])                       for every i
-        //   (root,i,j) -> level 3  : 4*3 + 4*(d + Dp[i] + Dp[j])              for every arc i->j of the rows
-        // (deeper internal nodes, K > 4, are counted as 4*(t+1) + 4*d each: a lower bound)
-        if (K >= 3) {
-            uint64_t b = 0;
-            for (int i = tid; i < d; i += BLOCK) {
-                b += 8ull + 4ull * ((uint64_t)d + Dp[i]);
-                if (K >= 4) {
-                    uint32_t out_i = 0;  // arcs leaving i
-                    for (int w = 0; w < W; ++w) out_i += __popc(clq_load<IN_LDS>(rows + (int64_t)i * W + w));
-                    b += (uint64_t)out_i * (12ull + 4ull * ((uint64_t)d + Dp[i])) + 4ull * (uint64_t)col[i] * Dp[i];
-                }
-            }
-            if (tid == 0) b += 4ull + 4ull * (uint64_t)d;
-            if (K >= 5 && lane == 0) b += nodes * (16ull + 4ull * (uint64_t)d);
-            bytes += b;
-        }
+        //   (root,i) -> level 2    : 4*2 + 4*(d + Dp[i])                  for every i
+        //   (root,i,j) -> level 3  : 4*3 + 4*(d + Dp[i] + Dp[j])         for every arc i->j (K >= 4)
+        //   deeper internal nodes (K >= 5) at 4*4 + 4*d each: a lower bound
+        uint64_t b = K >= 4 ? arcs_bytes : 0;
+        for (int i = tid; i < d; i += BLOCK) b += 8ull + 4ull * ((uint64_t)d + Dp[i]);
+        if (tid == 0) b += 4ull + 4ull * (uint64_t)d;
+        if (K >= 5 && lane == 0) b += nodes * (16ull + 4ull * (uint64_t)d);
+        bytes += b;
         __syncthreads();
     }
     total = wave_sum_u64(total);
