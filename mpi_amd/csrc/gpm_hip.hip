@@ -887,8 +887,8 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
 static size_t clq_lds_bytes(int K, int block, int dcap, bool rows_in_lds) {
     const size_t wcap = dcap / 32 < 4 ? 4 : dcap / 32;
     const size_t depths = K > 3 ? K - 3 : 1;
-    size_t words = 2 * (size_t)dcap + (size_t)(block / GPM_WAVE) * ((size_t)dcap / 2 + depths * wcap) +
-                   (rows_in_lds ? (size_t)dcap * wcap : 0);
+    const size_t work = std::max((size_t)(block / GPM_WAVE) * ((size_t)dcap / 2 + depths * wcap), 2 * (size_t)dcap);
+    size_t words = 2 * (size_t)dcap + work + (rows_in_lds ? (size_t)dcap * wcap : 0);
     return words * sizeof(uint32_t);
 }
 
@@ -898,18 +898,19 @@ static int clique_launch(DevState &d, const uint64_t n[5]) {
     unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + CLQ_SLOTS;
     const int32_t *l = d.clq_lists;
     const int64_t st = d.clq_stride;
+    const int bias = (int)env_i64("GPM_CLIQUE_PROBE_BIAS", 0);
     int rc;
     if (n[0]) {
         if ((rc = timed_begin(d, 0, (int64_t)n[0]))) return rc;
-        k_clique<K, 64, true><<<(unsigned)n[0], 64, clq_lds_bytes(K, 64, 64, true), s>>>(d.gv, l, (int64_t)n[0], 64, nullptr,
-                                                                                  cnt, byt);
+        k_clique<K, 64, true><<<(unsigned)n[0], 64, clq_lds_bytes(K, 64, 64, true), s>>>(d.gv, l, (int64_t)n[0], 64, bias,
+                                                                                     nullptr, cnt, byt);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d))) return rc;
     }
     if (n[1]) {
         if ((rc = timed_begin(d, 0, (int64_t)n[1]))) return rc;
-        k_clique<K, 256, true><<<(unsigned)n[1], 256, clq_lds_bytes(K, 256, 256, true), s>>>(d.gv, l + st, (int64_t)n[1], 256,
-                                                                                     nullptr, cnt, byt);
+        k_clique<K, 256, true><<<(unsigned)n[1], 256, clq_lds_bytes(K, 256, 256, true), s>>>(
+            d.gv, l + st, (int64_t)n[1], 256, bias, nullptr, cnt, byt);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d))) return rc;
     }
@@ -918,8 +919,8 @@ static int clique_launch(DevState &d, const uint64_t n[5]) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_clique<K, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
         if ((rc = timed_begin(d, 0, (int64_t)n[2]))) return rc;
-        k_clique<K, 512, true><<<(unsigned)n[2], 512, lds, s>>>(d.gv, l + 2 * st, (int64_t)n[2], 1024, nullptr, cnt,
-                                                                byt);
+        k_clique<K, 512, true><<<(unsigned)n[2], 512, lds, s>>>(d.gv, l + 2 * st, (int64_t)n[2], 1024, bias, nullptr,
+                                                                cnt, byt);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d))) return rc;
     }
@@ -927,7 +928,7 @@ static int clique_launch(DevState &d, const uint64_t n[5]) {
         unsigned blocks = (unsigned)std::min<uint64_t>(n[3], (uint64_t)d.clq_scratch_blocks);
         if ((rc = timed_begin(d, 0, (int64_t)n[3]))) return rc;
         k_clique<K, 256, false><<<blocks, 256, clq_lds_bytes(K, 256, CLQ_MAX_D, false), s>>>(
-            d.gv, l + 3 * st, (int64_t)n[3], CLQ_MAX_D, d.clq_scratch, cnt, byt);
+            d.gv, l + 3 * st, (int64_t)n[3], CLQ_MAX_D, bias, d.clq_scratch, cnt, byt);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d))) return rc;
     }

@@ -429,6 +429,32 @@ __device__ __forceinline__ u32x4 load4(const uint32_t *p) {
     return {v.x, v.y, v.z, v.w};
 }
 
+// Open-addressing hash of the universe U in LDS, used while the rows are built:
+// slot = (id & ~0xfff) | (position + 1), 0 = empty.  The 20 tag bits reject
+// almost every foreign id without touching U.
+__device__ __forceinline__ uint32_t clq_hash(int32_t id, int shift) { return ((uint32_t)id * 2654435761u) >> shift; }
+
+__device__ __forceinline__ void clq_hash_insert(uint32_t *tab, uint32_t mask, int shift, int32_t id, int pos) {
+    uint32_t s = clq_hash(id, shift);
+    const uint32_t val = ((uint32_t)id & ~0xfffu) | (uint32_t)(pos + 1);
+    while (atomicCAS(tab + s, 0u, val) != 0u) s = (s + 1) & mask;
+}
+
+// Position of id in U, or -1.
+__device__ __forceinline__ int clq_hash_find(const uint32_t *tab, uint32_t mask, int shift, const int32_t *U,
+                                             int32_t id) {
+    uint32_t s = clq_hash(id, shift);
+    for (;;) {
+        uint32_t x = tab[s];
+        if (x == 0u) return -1;
+        if (((x ^ (uint32_t)id) & ~0xfffu) == 0u) {
+            int pos = (int)(x & 0xfffu) - 1;
+            if (U[pos] == id) return pos;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
 // Geometry of one root's bitmaps.
 struct ClqGeom {
     int d;    // universe size
@@ -479,10 +505,16 @@ __device__ __forceinline__ uint64_t clq_count(u32x4 C, const uint32_t *c_words, 
         uint32_t acc = 0;
         const int G = GPM_WAVE >> q.lg;
         if (lane_ok) {
-            for (int t = lane >> q.lg; t < cnt; t += G) {
-                int j = ws.J[t];
-                acc += popc4(and4(C, load4(rows + (size_t)j * q.Wp + 4 * sub)));
+            const uint32_t *base = rows + 4 * sub;
+            int t = lane >> q.lg;
+            for (; t + 3 * G < cnt; t += 4 * G) {  // four independent row reads in flight
+                u32x4 r0 = load4(base + (size_t)ws.J[t] * q.Wp);
+                u32x4 r1 = load4(base + (size_t)ws.J[t + G] * q.Wp);
+                u32x4 r2 = load4(base + (size_t)ws.J[t + 2 * G] * q.Wp);
+                u32x4 r3 = load4(base + (size_t)ws.J[t + 3 * G] * q.Wp);
+                acc += popc4(and4(C, r0)) + popc4(and4(C, r1)) + popc4(and4(C, r2)) + popc4(and4(C, r3));
             }
+            for (; t < cnt; t += G) acc += popc4(and4(C, load4(base + (size_t)ws.J[t] * q.Wp)));
         }
         return acc;
     } else {
@@ -508,12 +540,14 @@ __device__ __forceinline__ uint64_t clq_count(u32x4 C, const uint32_t *c_words, 
 }
 
 // One workgroup (BLOCK threads) per root.  Dynamic LDS layout, 32-bit words:
-//   U[dcap] | Dp[dcap] | per wave: J[dcap/2] cbuf[(K-2) * wcap] | rows[dcap * wcap] (IN_LDS only)
-// With !IN_LDS the rows live in this workgroup's slab of `scratch`.
+//   U[dcap] | Dp[dcap] | work[max(NW * (dcap/2 + DEPTHS*wcap), 2*dcap)] | rows[dcap * wcap] (IN_LDS only)
+// `work` holds the hash of U while the rows are built and afterwards, per
+// wave, the expanded list J and the nested candidate sets.  With !IN_LDS the
+// rows live in this workgroup's slab of `scratch`.
 template <int K, int BLOCK, bool IN_LDS>
 __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
-                                                  uint32_t *scratch, unsigned long long *n_matches,
-                                                  unsigned long long *alg_bytes) {
+                                                  int probe_bias, uint32_t *scratch,
+                                                  unsigned long long *n_matches, unsigned long long *alg_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     constexpr int NW = BLOCK / GPM_WAVE;
     constexpr int DEPTHS = K > 3 ? K - 3 : 1;  // nested candidate sets kept in LDS
@@ -521,11 +555,15 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
     const int wcap = dcap / 32 < 4 ? 4 : dcap / 32;
     int32_t *U = (int32_t *)smem;
     uint32_t *Dp = smem + dcap;
-    uint32_t *wave_base = smem + 2 * dcap + (size_t)wave * (size_t)(dcap / 2 + DEPTHS * wcap);
+    uint32_t *work = smem + 2 * dcap;
+    const int per_wave = dcap / 2 + DEPTHS * wcap;
+    const int work_words = NW * per_wave > 2 * dcap ? NW * per_wave : 2 * dcap;
+    uint32_t *wave_base = work + (size_t)wave * (size_t)per_wave;
     ClqWave ws;
     ws.J = (uint16_t *)wave_base;
     ws.cbuf = wave_base + dcap / 2;
-    uint32_t *rows = IN_LDS ? smem + 2 * dcap + (size_t)NW * (size_t)(dcap / 2 + DEPTHS * wcap)
+    uint32_t *htab = work;
+    uint32_t *rows = IN_LDS ? work + work_words
                             : scratch + (size_t)blockIdx.x * ((size_t)CLQ_MAX_D * (CLQ_MAX_D / 32));
     const int64_t *off = g.off[0], *mid = g.mid[0];
     const int32_t *adj = g.adj[0];
@@ -540,10 +578,17 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
         q.lg = q.Wp <= 4 ? 0 : q.Wp <= 8 ? 1 : q.Wp <= 16 ? 2 : q.Wp <= 32 ? 3 : 4;
         q.L = 1 << q.lg;
         const int d = q.d, Wp = q.Wp;
+        int hbits = 1;  // table of 2^hbits >= 2*d slots
+        while ((1 << hbits) < 2 * d) ++hbits;
+        const uint32_t hmask = (1u << hbits) - 1;
+        const int hshift = 32 - hbits;
+        for (int i = tid; i <= (int)hmask; i += BLOCK) htab[i] = 0;
+        __syncthreads();
         for (int i = tid; i < d; i += BLOCK) {
             int32_t v = adj[ub + i];
             U[i] = v;
             Dp[i] = (uint32_t)(off[v + 1] - mid[v]);
+            clq_hash_insert(htab, hmask, hshift, v, i);
         }
         __syncthreads();
 
@@ -553,20 +598,38 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
             const int32_t v = U[i];
             uint32_t *row = rows + (size_t)i * Wp;
             const uint64_t per_arc = 12ull + 4ull * ((uint64_t)d + Dp[i]);
-            if (v >= g.hub_base) {
+            // a hub's row is gathered from the hub matrix when its list is long
+            // next to the number of positions to test (probe_bias/16 is the ratio)
+            if (v >= g.hub_base && (int64_t)Dp[i] * 16 >= (int64_t)probe_bias * (int64_t)(d - 1 - i)) {
                 const uint32_t *hrow = g.hub + (size_t)(v - g.hub_base) * (size_t)g.hub_wpr;
-                for (int j0 = 0; j0 < Wp * 32; j0 += GPM_WAVE) {
-                    const int j = j0 + lane;
-                    bool bit = false;
-                    if (j0 + GPM_WAVE > i + 1 && j > i && j < d) {
-                        uint32_t c = (uint32_t)(U[j] - g.hub_base);
-                        bit = (hrow[c >> 5] >> (c & 31)) & 1u;
+                // 256 positions per trip: four independent gathers in flight (Wp*32 is a multiple of 128)
+                for (int j0 = 0; j0 < Wp * 32; j0 += 4 * GPM_WAVE) {
+                    uint32_t word[4];
+                    uint32_t sh[4];
+                    bool live[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int j = j0 + k * GPM_WAVE + lane;
+                        live[k] = j > i && j < d;
+                        word[k] = 0;
+                        sh[k] = 0;
+                        if (live[k]) {
+                            uint32_t c = (uint32_t)(U[j] - g.hub_base);
+                            word[k] = hrow[c >> 5];
+                            sh[k] = c & 31;
+                        }
                     }
-                    unsigned long long mask = __ballot(bit);
-                    if (bit) arcs_bytes += per_arc + 4ull * Dp[j];
-                    if (lane == 0) {
-                        row[j0 >> 5] = (uint32_t)mask;
-                        row[(j0 >> 5) + 1] = (uint32_t)(mask >> 32);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int jb = j0 + k * GPM_WAVE;
+                        if (jb >= Wp * 32) break;
+                        const bool bit = live[k] && ((word[k] >> sh[k]) & 1u);
+                        unsigned long long mask = __ballot(bit);
+                        if (bit) arcs_bytes += per_arc + 4ull * Dp[jb + lane];
+                        if (lane == 0) {
+                            row[jb >> 5] = (uint32_t)mask;
+                            row[(jb >> 5) + 1] = (uint32_t)(mask >> 32);
+                        }
                     }
                 }
             } else {
@@ -575,9 +638,8 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
                 wave_lds_sync();
                 const int64_t vb = mid[v], ve = off[v + 1];
                 for (int64_t p = vb + lane; p < ve; p += GPM_WAVE) {
-                    int32_t c = adj[p];
-                    int j = lower_bound_s(U, i + 1, d, c);
-                    if (j < d && U[j] == c) {
+                    int j = clq_hash_find(htab, hmask, hshift, U, adj[p]);
+                    if (j >= 0) {
                         atomicOr(row + (j >> 5), 1u << (j & 31));
                         arcs_bytes += per_arc + 4ull * Dp[j];
                     }
