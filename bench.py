@@ -88,10 +88,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GPM_BENCH_BACKEND=gloo is for rehearsing N > 1 on a box with fewer GPUs than ranks
+    backend = os.environ.get("GPM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     t0 = time.time()
     off, adj = gen.rmat(args.scale, args.ef, seed=1, device=dev)
@@ -102,7 +109,7 @@ def main():
     torch.cuda.empty_cache()
     t_gen = time.time() - t0
     t0 = time.time()
-    matcher = binding.Matcher(1, devices=[local_rank])
+    matcher = binding.Matcher(1, devices=[dev_index])
     info = matcher.upload(n, off_h, adj_h)
     del off_h, adj_h
     plan = matcher.set_pattern(gen.PATTERNS[args.pattern])
@@ -113,11 +120,12 @@ def main():
 
     cursor = gdist.open_cursor(f"bench_{os.environ.get('MASTER_PORT', os.getpid())}")
     matcher.set_cursor(cursor.address)
+    matcher.set_chunks(32 * world)
 
     def step():
         gdist.reset_cursor(cursor)
         local = matcher.findMatches(count_only=True)
-        return gdist.all_reduce_count(local, device=dev)
+        return gdist.all_reduce_count(local, device=coll_dev)
 
     def fence():
         if world > 1:
@@ -140,7 +148,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = matcher.stats()

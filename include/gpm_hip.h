@@ -152,6 +152,12 @@ int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *plan);
  * assignNodesToProcesses, src/gpm-par.c:300-340). */
 int gpm_hip_set_cursor(gpm_ctx *ctx, volatile uint64_t *cursor);
 
+/* How many chunks to cut the root range into (0 = default, 32 per GPU of the
+ * context).  Chunks hold roots of similar estimated cost; processes that share
+ * a cursor must pass the same value (e.g. 32 x number of processes) so that
+ * they build the same chunk table. */
+int gpm_hip_set_chunks(gpm_ctx *ctx, int64_t n_chunks);
+
 /* Restrict roots to [lo, hi) of the library's root order (0 <= lo <= hi <= n);
  * default is all n.  Used for sharding tests. */
 int gpm_hip_set_roots(gpm_ctx *ctx, int64_t lo, int64_t hi);

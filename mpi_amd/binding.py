@@ -65,7 +65,7 @@ ROW_SINK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes
 # every symbol include/gpm_hip.h declares
 HIP_SYMBOLS = ["gpm_hip_last_error", "gpm_hip_device_count", "gpm_hip_create", "gpm_hip_destroy",
                "gpm_hip_upload_graph", "gpm_hip_graph_info", "gpm_hip_set_plan", "gpm_hip_set_cursor",
-               "gpm_hip_set_roots", "gpm_hip_search", "gpm_hip_stats"]
+               "gpm_hip_set_roots", "gpm_hip_set_chunks", "gpm_hip_search", "gpm_hip_stats"]
 
 _hip = None
 _host = None
@@ -87,6 +87,7 @@ def hip_lib():
         lib.gpm_hip_set_plan.argtypes = [ctypes.c_void_p, ctypes.POINTER(gpm_plan)]
         lib.gpm_hip_set_cursor.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.gpm_hip_set_roots.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+        lib.gpm_hip_set_chunks.argtypes = [ctypes.c_void_p, ctypes.c_int64]
         lib.gpm_hip_search.argtypes = [ctypes.c_void_p, ctypes.c_int, ROW_SINK, ctypes.c_void_p,
                                        ctypes.POINTER(ctypes.c_uint64)]
         lib.gpm_hip_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(gpm_stats)]
@@ -256,6 +257,9 @@ class Matcher:
 
     def set_roots(self, lo, hi):
         self._check(self.lib.gpm_hip_set_roots(self.ctx, lo, hi))
+
+    def set_chunks(self, n_chunks):
+        self._check(self.lib.gpm_hip_set_chunks(self.ctx, n_chunks))
 
     def set_cursor(self, address):
         self._check(self.lib.gpm_hip_set_cursor(self.ctx, address))

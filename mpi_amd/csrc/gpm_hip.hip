@@ -67,6 +67,25 @@ struct EventPair {
     int64_t rows;
 };
 
+// One chunk of the root range; in clique mode also its roots per size class.
+struct Chunk {
+    int64_t lo, hi;
+    uint32_t n[5];
+};
+
+// The clique path keeps several chunks in flight, each on its own stream with
+// its own root lists, so that the tail of one chunk's launches overlaps the
+// next chunk's.
+#define CLQ_INFLIGHT 4
+struct ChunkSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    int32_t *lists = nullptr;
+    unsigned long long *counts = nullptr;
+    uint32_t *scratch = nullptr;  // bitmap rows of the roots too large for LDS, one slab per workgroup
+    bool busy = false;
+};
+
 struct DevState {
     int dev = -1;
     hipStream_t stream = nullptr;
@@ -90,9 +109,8 @@ struct DevState {
     unsigned long long *ctr_host = nullptr;  // pinned mirror for read-back
     int64_t *i64_dev = nullptr, *i64_host = nullptr;
     // clique kernel: per-class root lists, global row scratch, spread result slots
-    int32_t *clq_lists = nullptr;
+    ChunkSlot slots[CLQ_INFLIGHT];
     int64_t clq_stride = 0;
-    uint32_t *clq_scratch = nullptr;
     int clq_scratch_blocks = 0;
     unsigned long long *clq_slots = nullptr;  // [0,CLQ_SLOTS) matches, [CLQ_SLOTS,2*CLQ_SLOTS) bytes
     std::vector<EventPair> events;
@@ -122,7 +140,10 @@ struct gpm_ctx {
     bool use_tail = true;
     int clique_k = 0;  // K when the plan is a K-clique under a total ordering, else 0
     bool use_clique = true;
-    int64_t chunk_roots = 1 << 16;
+    int64_t chunk_roots = 1 << 20;  // upper bound of a chunk's size
+    int64_t chunk_hint = 0;         // how many chunks to aim for (0 = 32 per GPU of the context)
+    std::vector<Chunk> chunks;
+    bool chunks_valid = false;
     int64_t root_lo = 0, root_hi = 0;
     volatile uint64_t *shared_cursor = nullptr;
     std::atomic<uint64_t> own_cursor{0};
@@ -192,11 +213,15 @@ static void free_buffers(DevState &d) {
         d.beg[k] = d.cnt[k] = d.pref[k] = nullptr;
     }
     dev_free(d.scan_tmp);
-    dev_free(d.clq_lists);
-    dev_free(d.clq_scratch);
+    for (auto &sl : d.slots) {
+        dev_free(sl.lists);
+        dev_free(sl.counts);
+        dev_free(sl.scratch);
+        sl.lists = nullptr;
+        sl.counts = nullptr;
+        sl.scratch = nullptr;
+    }
     dev_free(d.clq_slots);
-    d.clq_lists = nullptr;
-    d.clq_scratch = nullptr;
     d.clq_slots = nullptr;
     dev_free(d.emit);
     host_free(d.emit_host);
@@ -215,6 +240,10 @@ extern "C" void gpm_hip_destroy(gpm_ctx *ctx) {
         for (auto &ev : d.events) {
             (void)hipEventDestroy(ev.a);
             (void)hipEventDestroy(ev.b);
+        }
+        for (auto &sl : d.slots) {
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            if (sl.stream) (void)hipStreamDestroy(sl.stream);
         }
         dev_free(d.ctr);
         host_free(d.ctr_host);
@@ -244,13 +273,18 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
         if (e == hipSuccess) e = hipHostMalloc(&d.ctr_host, CTR_COUNT * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMalloc(&d.i64_dev, 4 * sizeof(int64_t));
         if (e == hipSuccess) e = hipHostMalloc(&d.i64_host, 4 * sizeof(int64_t));
+        for (auto &sl : d.slots) {
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+        }
         if (e != hipSuccess) {
             gpm_hip_destroy(ctx);
             return fail(GPM_ENODEV, "set-up of device %d failed: %s", d.dev, hipGetErrorString(e));
         }
     }
-    ctx->chunk_roots = env_i64("GPM_CHUNK_ROOTS", 1 << 16);
+    ctx->chunk_roots = env_i64("GPM_CHUNK_ROOTS", 1 << 20);
     if (ctx->chunk_roots < 1) ctx->chunk_roots = 1;
+    ctx->chunk_hint = env_i64("GPM_CHUNKS", 0);
     ctx->use_tail = env_i64("GPM_NO_TAIL", 0) == 0;
     ctx->use_clique = env_i64("GPM_NO_CLIQUE", 0) == 0;
     *out = ctx;
@@ -445,6 +479,7 @@ extern "C" int gpm_hip_upload_graph(gpm_ctx *ctx, int32_t n, const int64_t *out_
         return fail(GPM_EINVAL, "arc counts of the two directions differ");
     ctx->have_graph = false;
     ctx->have_plan = false;
+    ctx->chunks_valid = false;
     uint32_t flags = 0;
     for (auto &d : ctx->devs) {
         int rc = upload_one(d, n, out_off, out_adj, in_off, in_adj, labels, &flags);
@@ -524,6 +559,7 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
     if ((any_bound || p->n_aut > 1) && !ctx->info.simple)
         return fail(GPM_EINVAL, "ordering bounds need a data graph without duplicate arcs and self loops");
 
+    ctx->chunks_valid = false;
     ctx->plan = *p;
     ctx->aut.assign(p->aut ? p->aut : nullptr, p->aut ? p->aut + p->n_aut * (uint64_t)P : nullptr);
     ctx->plan.aut = ctx->aut.empty() ? nullptr : ctx->aut.data();
@@ -630,6 +666,15 @@ extern "C" int gpm_hip_set_roots(gpm_ctx *ctx, int64_t lo, int64_t hi) {
     if (lo < 0 || hi < lo || hi > ctx->info.n) return fail(GPM_EINVAL, "root range out of bounds");
     ctx->root_lo = lo;
     ctx->root_hi = hi;
+    ctx->chunks_valid = false;
+    return GPM_OK;
+}
+
+extern "C" int gpm_hip_set_chunks(gpm_ctx *ctx, int64_t n_chunks) {
+    if (!ctx) return fail(GPM_EINVAL, "null context");
+    if (n_chunks < 0) return fail(GPM_EINVAL, "chunk count must not be negative");
+    ctx->chunk_hint = n_chunks;
+    ctx->chunks_valid = false;
     return GPM_OK;
 }
 
@@ -675,13 +720,17 @@ static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
         d.scan_tmp_bytes = bytes ? bytes : 8;
         HIP_TRY(hipMalloc(&d.scan_tmp, d.scan_tmp_bytes));
     }
-    if (ctx->clique_k && !d.clq_lists) {
+    if (ctx->clique_k && !d.clq_slots) {
         d.clq_stride = ctx->chunk_roots;
-        HIP_TRY(hipMalloc(&d.clq_lists, (size_t)5 * (size_t)d.clq_stride * sizeof(int32_t)));
+        for (auto &sl : d.slots) {
+            HIP_TRY(hipMalloc(&sl.lists, (size_t)5 * (size_t)d.clq_stride * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&sl.counts, 8 * sizeof(unsigned long long)));
+        }
+        d.clq_scratch_blocks = (int)env_i64("GPM_CLIQUE_SCRATCH_BLOCKS", 512);
+        for (auto &sl : d.slots)
+            HIP_TRY(hipMalloc(&sl.scratch,
+                              (size_t)d.clq_scratch_blocks * (size_t)CLQ_MAX_D * (CLQ_MAX_D / 32) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&d.clq_slots, 2 * CLQ_SLOTS * sizeof(unsigned long long)));
-        d.clq_scratch_blocks = (int)env_i64("GPM_CLIQUE_SCRATCH_BLOCKS", 1024);
-        HIP_TRY(hipMalloc(&d.clq_scratch,
-                          (size_t)d.clq_scratch_blocks * (size_t)CLQ_MAX_D * (CLQ_MAX_D / 32) * sizeof(uint32_t)));
     }
     if (want_emit > d.cap_emit) {
         dev_free(d.emit);
@@ -703,7 +752,7 @@ static int read_ctr(DevState &d, int slot, uint64_t *out) {
     return GPM_OK;
 }
 
-static int timed_begin(DevState &d, int kind, int64_t rows = 0) {
+static int timed_begin(DevState &d, int kind, int64_t rows = 0, hipStream_t stream = nullptr) {
     if (d.events_used == d.events.size()) {
         EventPair ev{};
         ev.kind = kind;
@@ -713,12 +762,12 @@ static int timed_begin(DevState &d, int kind, int64_t rows = 0) {
     }
     d.events[d.events_used].kind = kind;
     d.events[d.events_used].rows = rows;
-    HIP_TRY(hipEventRecord(d.events[d.events_used].a, d.stream));
+    HIP_TRY(hipEventRecord(d.events[d.events_used].a, stream ? stream : d.stream));
     return GPM_OK;
 }
 
-static int timed_end(DevState &d) {
-    HIP_TRY(hipEventRecord(d.events[d.events_used].b, d.stream));
+static int timed_end(DevState &d, hipStream_t stream = nullptr) {
+    HIP_TRY(hipEventRecord(d.events[d.events_used].b, stream ? stream : d.stream));
     d.events_used++;
     return GPM_OK;
 }
@@ -893,85 +942,156 @@ static size_t clq_lds_bytes(int K, int block, int dcap, bool rows_in_lds) {
 }
 
 template <int K>
-static int clique_launch(DevState &d, const uint64_t n[5]) {
-    hipStream_t s = d.stream;
+static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[5]) {
+    hipStream_t s = sl.stream;
     unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + CLQ_SLOTS;
-    const int32_t *l = d.clq_lists;
+    const int32_t *l = sl.lists;
     const int64_t st = d.clq_stride;
     const int bias = (int)env_i64("GPM_CLIQUE_PROBE_BIAS", 0);
     int rc;
-    if (n[0]) {
-        if ((rc = timed_begin(d, 0, (int64_t)n[0]))) return rc;
-        k_clique<K, 64, true><<<(unsigned)n[0], 64, clq_lds_bytes(K, 64, 64, true), s>>>(d.gv, l, (int64_t)n[0], 64, bias,
-                                                                                     nullptr, cnt, byt);
+    if (n[3]) {  // longest-running class first
+        unsigned blocks = (unsigned)std::min<uint64_t>(n[3], (uint64_t)d.clq_scratch_blocks);
+        if ((rc = timed_begin(d, 0, (int64_t)n[3], s))) return rc;
+        k_clique<K, 256, false><<<blocks, 256, clq_lds_bytes(K, 256, CLQ_MAX_D, false), s>>>(
+            d.gv, l + 3 * st, (int64_t)n[3], CLQ_MAX_D, bias, sl.scratch, cnt, byt);
         HIP_TRY(hipGetLastError());
-        if ((rc = timed_end(d))) return rc;
-    }
-    if (n[1]) {
-        if ((rc = timed_begin(d, 0, (int64_t)n[1]))) return rc;
-        k_clique<K, 256, true><<<(unsigned)n[1], 256, clq_lds_bytes(K, 256, 256, true), s>>>(
-            d.gv, l + st, (int64_t)n[1], 256, bias, nullptr, cnt, byt);
-        HIP_TRY(hipGetLastError());
-        if ((rc = timed_end(d))) return rc;
+        if ((rc = timed_end(d, s))) return rc;
     }
     if (n[2]) {
         const size_t lds = clq_lds_bytes(K, 512, 1024, true);
         HIP_TRY(hipFuncSetAttribute((const void *)k_clique<K, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
-        if ((rc = timed_begin(d, 0, (int64_t)n[2]))) return rc;
+        if ((rc = timed_begin(d, 0, (int64_t)n[2], s))) return rc;
         k_clique<K, 512, true><<<(unsigned)n[2], 512, lds, s>>>(d.gv, l + 2 * st, (int64_t)n[2], 1024, bias, nullptr,
                                                                 cnt, byt);
         HIP_TRY(hipGetLastError());
-        if ((rc = timed_end(d))) return rc;
+        if ((rc = timed_end(d, s))) return rc;
     }
-    if (n[3]) {
-        unsigned blocks = (unsigned)std::min<uint64_t>(n[3], (uint64_t)d.clq_scratch_blocks);
-        if ((rc = timed_begin(d, 0, (int64_t)n[3]))) return rc;
-        k_clique<K, 256, false><<<blocks, 256, clq_lds_bytes(K, 256, CLQ_MAX_D, false), s>>>(
-            d.gv, l + 3 * st, (int64_t)n[3], CLQ_MAX_D, bias, d.clq_scratch, cnt, byt);
+    if (n[1]) {
+        if ((rc = timed_begin(d, 0, (int64_t)n[1], s))) return rc;
+        k_clique<K, 256, true><<<(unsigned)n[1], 256, clq_lds_bytes(K, 256, 256, true), s>>>(
+            d.gv, l + st, (int64_t)n[1], 256, bias, nullptr, cnt, byt);
         HIP_TRY(hipGetLastError());
-        if ((rc = timed_end(d))) return rc;
+        if ((rc = timed_end(d, s))) return rc;
+    }
+    if (n[0]) {
+        if ((rc = timed_begin(d, 0, (int64_t)n[0], s))) return rc;
+        k_clique<K, 64, true><<<(unsigned)n[0], 64, clq_lds_bytes(K, 64, 64, true), s>>>(d.gv, l, (int64_t)n[0], 64, bias,
+                                                                                     nullptr, cnt, byt);
+        HIP_TRY(hipGetLastError());
+        if ((rc = timed_end(d, s))) return rc;
     }
     return GPM_OK;
 }
 
 static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows);
 
-// One chunk of roots through the bitmap kernel; roots whose N+ exceeds the
-// kernel's universe go through the generic level-by-level path instead.
-static int clique_chunk(const SearchArgs &a, DevState &d, int64_t lo, int64_t hi) {
+static int clique_max_d() {
+    return (int)std::min<int64_t>(CLQ_MAX_D, std::max<int64_t>(0, env_i64("GPM_CLIQUE_MAX_D", CLQ_MAX_D)));
+}
+
+// One chunk of roots through the bitmap kernel, enqueued on the slot's stream
+// without any host round trip: the per-class root counts come from the chunk
+// table.  Roots whose N+ exceeds the kernel's universe (class 4) go through
+// the generic level-by-level path instead.
+static int clique_chunk(const SearchArgs &a, DevState &d, ChunkSlot &sl, const Chunk &ch) {
     gpm_ctx *ctx = a.ctx;
-    hipStream_t s = d.stream;
-    HIP_TRY(hipMemsetAsync(d.ctr + CTR_CLQ_CLASS0, 0, 5 * sizeof(unsigned long long), s));
-    const int max_d = (int)std::min<int64_t>(CLQ_MAX_D, std::max<int64_t>(0, env_i64("GPM_CLIQUE_MAX_D", CLQ_MAX_D)));
-    k_clique_bin<<<grid_for(hi - lo), 256, 0, s>>>(d.gv, ctx->clique_k, max_d, lo, hi, d.clq_lists, d.clq_stride,
-                                                   d.ctr + CTR_CLQ_CLASS0);
+    hipStream_t s = sl.stream;
+    HIP_TRY(hipMemsetAsync(sl.counts, 0, 8 * sizeof(unsigned long long), s));
+    k_clique_bin<<<grid_for(ch.hi - ch.lo), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(), ch.lo, ch.hi, sl.lists,
+                                                         d.clq_stride, sl.counts);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(d.ctr_host + CTR_CLQ_CLASS0, d.ctr + CTR_CLQ_CLASS0, 5 * sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    uint64_t n[5];
-    for (int c = 0; c < 5; ++c) n[c] = d.ctr_host[CTR_CLQ_CLASS0 + c];
-    d.rows_in[0] += n[0] + n[1] + n[2] + n[3];
+    d.rows_in[0] += (uint64_t)ch.n[0] + ch.n[1] + ch.n[2] + ch.n[3];
     int rc = GPM_OK;
     switch (ctx->clique_k) {
-        case 3: rc = clique_launch<3>(d, n); break;
-        case 4: rc = clique_launch<4>(d, n); break;
-        case 5: rc = clique_launch<5>(d, n); break;
-        case 6: rc = clique_launch<6>(d, n); break;
-        case 7: rc = clique_launch<7>(d, n); break;
-        case 8: rc = clique_launch<8>(d, n); break;
-        case 9: rc = clique_launch<9>(d, n); break;
-        case 10: rc = clique_launch<10>(d, n); break;
+        case 3: rc = clique_launch<3>(d, sl, ch.n); break;
+        case 4: rc = clique_launch<4>(d, sl, ch.n); break;
+        case 5: rc = clique_launch<5>(d, sl, ch.n); break;
+        case 6: rc = clique_launch<6>(d, sl, ch.n); break;
+        case 7: rc = clique_launch<7>(d, sl, ch.n); break;
+        case 8: rc = clique_launch<8>(d, sl, ch.n); break;
+        case 9: rc = clique_launch<9>(d, sl, ch.n); break;
+        case 10: rc = clique_launch<10>(d, sl, ch.n); break;
         default: return fail(GPM_ERUNTIME, "clique size %d not supported", ctx->clique_k);
     }
     if (rc) return rc;
-    if (n[4]) {
-        HIP_TRY(hipMemcpyAsync(d.F[0], d.clq_lists + 4 * d.clq_stride, (size_t)n[4] * sizeof(int32_t),
-                               hipMemcpyDeviceToDevice, s));
-        rc = expand(a, d, 1, (int64_t)n[4]);
+    if (ch.n[4]) {
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpyAsync(d.F[0], sl.lists + 4 * d.clq_stride, (size_t)ch.n[4] * sizeof(int32_t),
+                               hipMemcpyDeviceToDevice, d.stream));
+        rc = expand(a, d, 1, (int64_t)ch.n[4]);
     }
     return rc;
+}
+
+// Cut the root range into chunks of similar estimated cost (heaviest roots
+// first, so early chunks are short), capped at chunk_roots roots each.  Every
+// context over the same graph, plan, root range and hint builds the same table,
+// which is what lets several processes share one cursor.
+static int prepare_chunks(gpm_ctx *ctx) {
+    DevState &d = ctx->devs[0];
+    HIP_TRY(hipSetDevice(d.dev));
+    hipStream_t s = d.stream;
+    ctx->chunks.clear();
+    const int64_t lo = ctx->root_lo, hi = ctx->root_hi, nroots = hi - lo;
+    if (nroots <= 0) {
+        ctx->chunks_valid = true;
+        return GPM_OK;
+    }
+    const int P = ctx->pv.P;
+    const bool oriented = P > 1 && ctx->pv.lv[1].src_part == PART_ABOVE;
+    const int min_d = ctx->clique_k && ctx->use_clique ? ctx->clique_k - 1 : 0;
+    int64_t *cost = nullptr, *pref = nullptr;
+    HIP_TRY(hipMalloc(&cost, (size_t)nroots * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&pref, (size_t)nroots * sizeof(int64_t)));
+    k_root_cost<<<grid_for(nroots), 256, 0, s>>>(d.gv, oriented, min_d, lo, hi, cost);
+    size_t tmp_bytes = 0;
+    void *tmp = nullptr;
+    HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, cost, pref, (size_t)nroots, rocprim::plus<int64_t>(), s));
+    HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+    HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, cost, pref, (size_t)nroots, rocprim::plus<int64_t>(), s));
+    std::vector<int64_t> hpref((size_t)nroots);
+    HIP_TRY(hipMemcpyAsync(hpref.data(), pref, (size_t)nroots * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipFree(tmp));
+    HIP_TRY(hipFree(cost));
+    HIP_TRY(hipFree(pref));
+    const int64_t want = ctx->chunk_hint > 0 ? ctx->chunk_hint : 32 * (int64_t)ctx->devs.size();
+    const int64_t target = std::max<int64_t>(1, hpref.back() / want);
+    int64_t begin = 0;
+    while (begin < nroots) {
+        const int64_t base = begin ? hpref[(size_t)begin - 1] : 0;
+        // first index whose prefix reaches base + target
+        int64_t end = std::lower_bound(hpref.begin() + begin, hpref.end(), base + target) - hpref.begin() + 1;
+        end = std::min({end, nroots, begin + ctx->chunk_roots});
+        Chunk c{};
+        c.lo = lo + begin;
+        c.hi = lo + end;
+        ctx->chunks.push_back(c);
+        begin = end;
+    }
+    if (ctx->clique_k && ctx->use_clique) {
+        const int nch = (int)ctx->chunks.size();
+        std::vector<int64_t> bounds((size_t)nch);
+        for (int i = 0; i < nch; ++i) bounds[(size_t)i] = ctx->chunks[(size_t)i].lo;
+        int64_t *dbounds = nullptr;
+        unsigned int *table = nullptr;
+        HIP_TRY(hipMalloc(&dbounds, (size_t)nch * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(&table, (size_t)nch * 5 * sizeof(unsigned int)));
+        HIP_TRY(hipMemcpyAsync(dbounds, bounds.data(), (size_t)nch * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(table, 0, (size_t)nch * 5 * sizeof(unsigned int), s));
+        k_chunk_classes<<<grid_for(nroots), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(), lo, hi, dbounds, nch,
+                                                         table);
+        std::vector<unsigned int> htable((size_t)nch * 5);
+        HIP_TRY(hipMemcpyAsync(htable.data(), table, htable.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipFree(dbounds));
+        HIP_TRY(hipFree(table));
+        for (int i = 0; i < nch; ++i)
+            for (int c = 0; c < 5; ++c) ctx->chunks[(size_t)i].n[c] = htable[(size_t)i * 5 + (size_t)c];
+    }
+    ctx->chunks_valid = true;
+    return GPM_OK;
 }
 
 static uint64_t claim_chunk(gpm_ctx *ctx) {
@@ -995,17 +1115,26 @@ static int device_search(const SearchArgs &a, DevState &d) {
     uint64_t p1_rows = 0;
     const bool clique = a.count_only && ctx->clique_k >= 3 && ctx->use_clique;
     if (clique) HIP_TRY(hipMemsetAsync(d.clq_slots, 0, 2 * CLQ_SLOTS * sizeof(unsigned long long), s));
+    HIP_TRY(hipStreamSynchronize(s));  // counters are zero before any slot stream adds to them
+    uint64_t seq = 0;
     while (!ctx->stop) {
         const uint64_t c = claim_chunk(ctx);
-        const int64_t lo = ctx->root_lo + (int64_t)c * ctx->chunk_roots;
-        if (lo >= ctx->root_hi || (int64_t)c < 0) break;
-        const int64_t hi = std::min(ctx->root_hi, lo + ctx->chunk_roots);
+        if (c >= ctx->chunks.size()) break;
+        const Chunk &ch = ctx->chunks[(size_t)c];
+        const int64_t lo = ch.lo, hi = ch.hi;
         d.chunks++;
         if (clique) {
-            rc = clique_chunk(a, d, lo, hi);
+            ChunkSlot &sl = d.slots[seq++ % CLQ_INFLIGHT];
+            if (sl.busy) {  // at most CLQ_INFLIGHT chunks ahead of the GPU
+                HIP_TRY(hipEventSynchronize(sl.done));
+                sl.busy = false;
+            }
+            rc = clique_chunk(a, d, sl, ch);
             if (rc) return rc;
+            HIP_TRY(hipEventRecord(sl.done, sl.stream));
+            sl.busy = true;
             if (d.events_used > 4096) {
-                HIP_TRY(hipStreamSynchronize(s));
+                for (auto &x : d.slots) HIP_TRY(hipStreamSynchronize(x.stream));
                 if ((rc = collect_times(d))) return rc;
             }
             continue;
@@ -1041,6 +1170,10 @@ static int device_search(const SearchArgs &a, DevState &d) {
         }
     }
     if (clique) {
+        for (auto &x : d.slots) {
+            HIP_TRY(hipStreamSynchronize(x.stream));
+            x.busy = false;
+        }
         k_sum_slots<<<1, 64, 0, s>>>(d.clq_slots, CLQ_SLOTS, d.ctr + CTR_TAIL_MATCHES);
         k_sum_slots<<<1, 64, 0, s>>>(d.clq_slots + CLQ_SLOTS, CLQ_SLOTS, d.ctr + CTR_TAIL_BYTES);
     }
@@ -1063,6 +1196,10 @@ extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, v
     const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     ctx->stop = false;
     ctx->own_cursor = 0;
+    if (!ctx->chunks_valid) {
+        int prc = prepare_chunks(ctx);
+        if (prc) return prc;
+    }
     SearchArgs a{ctx, count_only != 0, ctx->devs.size() == 1, sink, user};
     int rc = GPM_OK;
     if (ctx->devs.size() == 1) {

@@ -419,6 +419,36 @@ __global__ void k_clique_bin(GraphView g, int K, int max_d, int64_t lo, int64_t 
     }
 }
 
+// Work estimate of every root of [lo, hi) (root index i is vertex n-1-i),
+// used to cut the root range into chunks of similar cost: the square of the
+// list the root's search walks first (N+ under ordering bounds), so a chunk of
+// hubs holds few roots and a chunk of leaves holds many.
+__global__ void k_root_cost(GraphView g, int oriented, int min_d, int64_t lo, int64_t hi, int64_t *cost) {
+    int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    int32_t v = (int32_t)(g.n - 1 - i);
+    int64_t d = g.off[0][v + 1] - (oriented ? g.mid[0][v] : g.off[0][v]);
+    cost[i - lo] = d < min_d ? 1 : d * d + 8;
+}
+
+// Size-class histogram of the roots of every chunk (the classes of k_clique_bin).
+__global__ void k_chunk_classes(GraphView g, int K, int max_d, int64_t lo, int64_t hi, const int64_t *bounds,
+                                int nchunks, unsigned int *table) {
+    int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    int32_t v = (int32_t)(g.n - 1 - i);
+    int64_t d = g.off[0][v + 1] - g.mid[0][v];
+    if (d < K - 1) return;
+    int cls = d > max_d ? 4 : d <= 64 ? 0 : d <= 256 ? 1 : d <= 1024 ? 2 : 3;
+    int a = 0, b = nchunks;  // last chunk whose first root is <= i
+    while (b - a > 1) {
+        int m = (a + b) >> 1;
+        if (bounds[m] <= i) a = m;
+        else b = m;
+    }
+    atomicAdd(table + a * 5 + cls, 1u);
+}
+
 struct u32x4 {
     uint32_t x, y, z, w;
 };
