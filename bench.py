@@ -120,7 +120,7 @@ def main():
 
     cursor = gdist.open_cursor(f"bench_{os.environ.get('MASTER_PORT', os.getpid())}")
     matcher.set_cursor(cursor.address)
-    matcher.set_chunks(32 * world)
+    matcher.set_chunks(int(os.environ.get("GPM_BENCH_CHUNKS", 32 * world)))
 
     def step():
         gdist.reset_cursor(cursor)

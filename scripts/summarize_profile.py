@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Condense a scripts/profile.sh run (gpurun_out/prof_<tag>/) into the files kept
+under profiles/: the rocprofv3 per-kernel time table, the counter sums of the
+search kernels, and the HBM bytes per launch that bench.py reports as
+roofline.traffic.
+
+Counter corrections (MI355X, measured by scripts/calib_fetch under the same
+tool): FETCH_SIZE is in KiB and reads exactly half of the bytes of coalesced 4-
+and 16-byte-per-lane streams, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE
+is in KiB and exact for coalesced stores."""
+import collections
+import csv
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = os.path.join("gpurun_out", f"prof_{tag}")
+dst = "profiles"
+os.makedirs(dst, exist_ok=True)
+SEARCH = ("k_clique", "k_tail", "k_extend", "k_ranges", "k_filter_roots", "k_batch_end", "k_sum_slots")
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+def counters(sub):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.Counter()
+    with open(os.path.join(src, sub, "t_counter_collection.csv")) as f:
+        seen = set()
+        for r in csv.DictReader(f):
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if (r["Dispatch_Id"], r["Counter_Name"]) not in seen and r["Counter_Name"] == list(agg[k])[0]:
+                calls[k] += 1
+            seen.add((r["Dispatch_Id"], r["Counter_Name"]))
+    return agg, calls
+
+
+# 1. per-kernel time table as rocprofv3 printed it (top rows + every search kernel)
+rows = list(csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))))
+keep = [r for i, r in enumerate(rows) if i < 12 or short(r["Name"]).startswith(SEARCH)]
+with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    w.writeheader()
+    for r in keep:
+        r = dict(r)
+        r["Name"] = short(r["Name"])
+        w.writerow(r)
+
+# 2. counters of the search kernels
+fetch, fcalls = counters("fetch")
+write, _ = counters("write")
+sq, _ = counters("sq")
+trace = {short(r["Name"]): r for r in rows}
+summary = {}
+for k in sorted(set(fetch) | set(sq)):
+    if not k.startswith(SEARCH):
+        continue
+    t = trace.get(k, {})
+    calls = int(t.get("Calls", fcalls[k]) or 0)
+    rd = 2.0 * fetch[k].get("FETCH_SIZE", 0.0) * 1024.0
+    wr = write[k].get("WRITE_SIZE", 0.0) * 1024.0
+    s = sq[k]
+    summary[k] = {
+        "calls": calls,
+        "total_ms": float(t.get("TotalDurationNs", 0)) / 1e6,
+        "avg_ms": float(t.get("AverageNs", 0)) / 1e6,
+        "hbm_read_bytes": rd, "hbm_write_bytes": wr,
+        "FETCH_SIZE_KiB_raw": fetch[k].get("FETCH_SIZE", 0.0), "WRITE_SIZE_KiB_raw": write[k].get("WRITE_SIZE", 0.0),
+        "SQ_LDS_BANK_CONFLICT": s.get("SQ_LDS_BANK_CONFLICT", 0.0), "SQ_LDS_IDX_ACTIVE": s.get("SQ_LDS_IDX_ACTIVE", 0.0),
+        "lds_conflict_share": (s.get("SQ_LDS_BANK_CONFLICT", 0.0) / s["SQ_LDS_IDX_ACTIVE"]) if s.get("SQ_LDS_IDX_ACTIVE") else None,
+        "SQ_INSTS_LDS": s.get("SQ_INSTS_LDS", 0.0), "SQ_INSTS_VALU": s.get("SQ_INSTS_VALU", 0.0),
+        "SQ_WAVES": s.get("SQ_WAVES", 0.0), "SQ_WAVE_CYCLES": s.get("SQ_WAVE_CYCLES", 0.0),
+        "SQ_BUSY_CYCLES": s.get("SQ_BUSY_CYCLES", 0.0), "SQ_WAIT_INST_LDS": s.get("SQ_WAIT_INST_LDS", 0.0),
+    }
+with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
+    json.dump(summary, f, indent=1)
+    f.write("\n")
+
+# 3. HBM bytes per launch of the intersection kernel (all size classes together),
+#    the same "per launch" basis as bench.py's roofline.achieved
+tail = [v for k, v in summary.items() if k.startswith(("k_clique<", "k_tail"))]
+calls = sum(v["calls"] for v in tail)
+hbm = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in tail)
+ms = sum(v["total_ms"] for v in tail)
+with open(os.path.join(dst, "tail_traffic.json"), "w") as f:
+    json.dump({"source": f"profiles/{tag}_pmc_summary.json", "launches": calls, "hbm_bytes_total": hbm,
+               "hbm_bytes_per_launch": hbm / calls if calls else None, "kernel_ms_total": ms,
+               "kernel_avg_ms": ms / calls if calls else None,
+               "note": "read bytes = 2 x FETCH_SIZE KiB (gfx950 correction, calibrated with scripts/calib_fetch), "
+                       "write bytes = WRITE_SIZE KiB; one benchmark step"}, f, indent=1)
+    f.write("\n")
+for name in ("trace.json",):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        with open(p) as fi, open(os.path.join(dst, f"{tag}_bench_under_trace.json"), "w") as fo:
+            fo.write(fi.read())
+print(json.dumps({k: {"calls": v["calls"], "total_ms": round(v["total_ms"], 2), "GB_read": round(v["hbm_read_bytes"] / 1e9, 2),
+                      "GB_written": round(v["hbm_write_bytes"] / 1e9, 3), "lds_conflict_share": v["lds_conflict_share"]}
+                  for k, v in summary.items()}, indent=1))
