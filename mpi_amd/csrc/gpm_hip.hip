@@ -70,19 +70,21 @@ struct EventPair {
 // One chunk of the root range; in clique mode also its roots per size class.
 struct Chunk {
     int64_t lo, hi;
-    uint32_t n[5];
+    uint32_t n[6];
 };
 
 // The clique path keeps several chunks in flight, each on its own stream with
 // its own root lists, so that the tail of one chunk's launches overlaps the
 // next chunk's.
 #define CLQ_INFLIGHT 4
+#define CLQ_ROWS_WORDS ((size_t)1 << 29)  // rows buffer per in-flight chunk: 2 GiB
 struct ChunkSlot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     int32_t *lists = nullptr;
     unsigned long long *counts = nullptr;
     uint32_t *scratch = nullptr;  // bitmap rows of the roots too large for LDS, one slab per workgroup
+    uint32_t *rows = nullptr;     // rows buffer of the build/count kernel pair
     bool busy = false;
 };
 
@@ -217,6 +219,8 @@ static void free_buffers(DevState &d) {
         dev_free(sl.lists);
         dev_free(sl.counts);
         dev_free(sl.scratch);
+        dev_free(sl.rows);
+        sl.rows = nullptr;
         sl.lists = nullptr;
         sl.counts = nullptr;
         sl.scratch = nullptr;
@@ -723,7 +727,8 @@ static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
     if (ctx->clique_k && !d.clq_slots) {
         d.clq_stride = ctx->chunk_roots;
         for (auto &sl : d.slots) {
-            HIP_TRY(hipMalloc(&sl.lists, (size_t)5 * (size_t)d.clq_stride * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&sl.lists, (size_t)CLQ_CLASSES * (size_t)d.clq_stride * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&sl.rows, (size_t)CLQ_ROWS_WORDS * sizeof(uint32_t)));
             HIP_TRY(hipMalloc(&sl.counts, 8 * sizeof(unsigned long long)));
         }
         d.clq_scratch_blocks = (int)env_i64("GPM_CLIQUE_SCRATCH_BLOCKS", 512);
@@ -941,31 +946,78 @@ static size_t clq_lds_bytes(int K, int block, int dcap, bool rows_in_lds) {
     return words * sizeof(uint32_t);
 }
 
+// Classes 2..4 of a chunk through the build/count kernel pair (K = 3: the
+// build kernel counts the triangles itself; K = 4: tiled count).
 template <int K>
-static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[5]) {
+static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[6], int bias) {
+    static_assert(K == 3 || K == 4, "build/count pair exists for triangles and 4-cliques");
+    hipStream_t s = sl.stream;
+    unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + CLQ_SLOTS;
+    const int dcaps[3] = {512, 1024, 2048};
+    const int64_t strides[3] = {512 * 16, 1024 * 32, 1024 * 32 + 2048 * 32};
+    constexpr int SEG = 4;
+    int rc;
+    for (int c = 4; c >= 2; --c) {  // longest-running class first
+        if (!n[c]) continue;
+        const int dcap = dcaps[c - 2];
+        const int64_t stride = strides[c - 2];
+        const int64_t batch = (int64_t)(CLQ_ROWS_WORDS / (size_t)stride);
+        const int32_t *list = sl.lists + (int64_t)c * d.clq_stride;
+        const size_t lds_build = ((size_t)4 * dcap + 4 * 64) * sizeof(uint32_t);
+        const size_t lds_count = ((size_t)8 * 512 + (size_t)std::min(dcap, 1024) * (std::min(dcap, 1024) / 32)) *
+                                 sizeof(uint32_t);
+        const int phases = dcap > 1024 ? 3 : 1;
+        for (int64_t b0 = 0; b0 < (int64_t)n[c]; b0 += batch) {
+            const int64_t nb = std::min<int64_t>(batch, (int64_t)n[c] - b0);
+            if ((rc = timed_begin(d, 0, nb, s))) return rc;
+            k_clq_build<K><<<(unsigned)(nb * (dcap / BIG_ROWS_PER_WG)), 256, lds_build, s>>>(
+                d.gv, list + b0, nb, dcap, bias, sl.rows, stride, cnt, byt);
+            HIP_TRY(hipGetLastError());
+            if ((rc = timed_end(d, s))) return rc;
+            if (K == 4) {
+                HIP_TRY(hipFuncSetAttribute((const void *)k_clq_count4<SEG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds_count));
+                if ((rc = timed_begin(d, 0, nb, s))) return rc;
+                k_clq_count4<SEG><<<(unsigned)(nb * phases * SEG), 512, lds_count, s>>>(d.gv, list + b0, nb, dcap,
+                                                                                        sl.rows, stride, cnt);
+                HIP_TRY(hipGetLastError());
+                if ((rc = timed_end(d, s))) return rc;
+            }
+        }
+    }
+    return GPM_OK;
+}
+
+template <int K>
+static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[6]) {
     hipStream_t s = sl.stream;
     unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + CLQ_SLOTS;
     const int32_t *l = sl.lists;
     const int64_t st = d.clq_stride;
     const int bias = (int)env_i64("GPM_CLIQUE_PROBE_BIAS", 0);
     int rc;
-    if (n[3]) {  // longest-running class first
-        unsigned blocks = (unsigned)std::min<uint64_t>(n[3], (uint64_t)d.clq_scratch_blocks);
-        if ((rc = timed_begin(d, 0, (int64_t)n[3], s))) return rc;
-        k_clique<K, 256, false><<<blocks, 256, clq_lds_bytes(K, 256, CLQ_MAX_D, false), s>>>(
-            d.gv, l + 3 * st, (int64_t)n[3], CLQ_MAX_D, bias, sl.scratch, cnt, byt);
-        HIP_TRY(hipGetLastError());
-        if ((rc = timed_end(d, s))) return rc;
-    }
-    if (n[2]) {
-        const size_t lds = clq_lds_bytes(K, 512, 1024, true);
-        HIP_TRY(hipFuncSetAttribute((const void *)k_clique<K, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        if ((rc = timed_begin(d, 0, (int64_t)n[2], s))) return rc;
-        k_clique<K, 512, true><<<(unsigned)n[2], 512, lds, s>>>(d.gv, l + 2 * st, (int64_t)n[2], 1024, bias, nullptr,
-                                                                cnt, byt);
-        HIP_TRY(hipGetLastError());
-        if ((rc = timed_end(d, s))) return rc;
+    if constexpr (K == 3 || K == 4) {
+        if ((rc = clique_launch_big<K>(d, sl, n, bias))) return rc;
+    } else {
+        if (n[4]) {  // rows in global scratch, persistent workgroups
+            unsigned blocks = (unsigned)std::min<uint64_t>(n[4], (uint64_t)d.clq_scratch_blocks);
+            if ((rc = timed_begin(d, 0, (int64_t)n[4], s))) return rc;
+            k_clique<K, 256, false><<<blocks, 256, clq_lds_bytes(K, 256, CLQ_MAX_D, false), s>>>(
+                d.gv, l + 4 * st, (int64_t)n[4], CLQ_MAX_D, bias, sl.scratch, cnt, byt);
+            HIP_TRY(hipGetLastError());
+            if ((rc = timed_end(d, s))) return rc;
+        }
+        for (int c = 3; c >= 2; --c) {
+            if (!n[c]) continue;
+            const size_t lds = clq_lds_bytes(K, 512, 1024, true);
+            HIP_TRY(hipFuncSetAttribute((const void *)k_clique<K, 512, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if ((rc = timed_begin(d, 0, (int64_t)n[c], s))) return rc;
+            k_clique<K, 512, true><<<(unsigned)n[c], 512, lds, s>>>(d.gv, l + c * st, (int64_t)n[c], 1024, bias,
+                                                                    nullptr, cnt, byt);
+            HIP_TRY(hipGetLastError());
+            if ((rc = timed_end(d, s))) return rc;
+        }
     }
     if (n[1]) {
         if ((rc = timed_begin(d, 0, (int64_t)n[1], s))) return rc;
@@ -1001,7 +1053,7 @@ static int clique_chunk(const SearchArgs &a, DevState &d, ChunkSlot &sl, const C
     k_clique_bin<<<grid_for(ch.hi - ch.lo), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(), ch.lo, ch.hi, sl.lists,
                                                          d.clq_stride, sl.counts);
     HIP_TRY(hipGetLastError());
-    d.rows_in[0] += (uint64_t)ch.n[0] + ch.n[1] + ch.n[2] + ch.n[3];
+    d.rows_in[0] += (uint64_t)ch.n[0] + ch.n[1] + ch.n[2] + ch.n[3] + ch.n[4];
     int rc = GPM_OK;
     switch (ctx->clique_k) {
         case 3: rc = clique_launch<3>(d, sl, ch.n); break;
@@ -1015,11 +1067,11 @@ static int clique_chunk(const SearchArgs &a, DevState &d, ChunkSlot &sl, const C
         default: return fail(GPM_ERUNTIME, "clique size %d not supported", ctx->clique_k);
     }
     if (rc) return rc;
-    if (ch.n[4]) {
+    if (ch.n[5]) {
         HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipMemcpyAsync(d.F[0], sl.lists + 4 * d.clq_stride, (size_t)ch.n[4] * sizeof(int32_t),
+        HIP_TRY(hipMemcpyAsync(d.F[0], sl.lists + 5 * d.clq_stride, (size_t)ch.n[5] * sizeof(int32_t),
                                hipMemcpyDeviceToDevice, d.stream));
-        rc = expand(a, d, 1, (int64_t)ch.n[4]);
+        rc = expand(a, d, 1, (int64_t)ch.n[5]);
     }
     return rc;
 }
@@ -1077,18 +1129,18 @@ static int prepare_chunks(gpm_ctx *ctx) {
         int64_t *dbounds = nullptr;
         unsigned int *table = nullptr;
         HIP_TRY(hipMalloc(&dbounds, (size_t)nch * sizeof(int64_t)));
-        HIP_TRY(hipMalloc(&table, (size_t)nch * 5 * sizeof(unsigned int)));
+        HIP_TRY(hipMalloc(&table, (size_t)nch * 6 * sizeof(unsigned int)));
         HIP_TRY(hipMemcpyAsync(dbounds, bounds.data(), (size_t)nch * sizeof(int64_t), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemsetAsync(table, 0, (size_t)nch * 5 * sizeof(unsigned int), s));
+        HIP_TRY(hipMemsetAsync(table, 0, (size_t)nch * 6 * sizeof(unsigned int), s));
         k_chunk_classes<<<grid_for(nroots), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(), lo, hi, dbounds, nch,
                                                          table);
-        std::vector<unsigned int> htable((size_t)nch * 5);
+        std::vector<unsigned int> htable((size_t)nch * 6);
         HIP_TRY(hipMemcpyAsync(htable.data(), table, htable.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipFree(dbounds));
         HIP_TRY(hipFree(table));
         for (int i = 0; i < nch; ++i)
-            for (int c = 0; c < 5; ++c) ctx->chunks[(size_t)i].n[c] = htable[(size_t)i * 5 + (size_t)c];
+            for (int c = 0; c < 6; ++c) ctx->chunks[(size_t)i].n[c] = htable[(size_t)i * 6 + (size_t)c];
     }
     ctx->chunks_valid = true;
     return GPM_OK;

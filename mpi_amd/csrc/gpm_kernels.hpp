@@ -393,11 +393,12 @@ __global__ void k_hub_fill(GraphView g, uint32_t *bits) {
 
 #define CLQ_MAX_D 2048                 // largest universe (bits per row)
 #define CLQ_SLOTS 1024                 // result counters are spread over this many slots
+#define CLQ_CLASSES 6
 
 // Sort roots of a chunk into size classes by d = |N+(root)|; each class is a
 // compacted list (ballot + prefix popcount, one atomic per wave and class).
-//   class 0: K-1 <= d <= 64      class 1: d <= 256      class 2: d <= 1024
-//   class 3: d <= max_d <= CLQ_MAX_D (rows in global scratch)   class 4: larger (generic path)
+//   class 0: K-1 <= d <= 64   1: d <= 256   2: d <= 512   3: d <= 1024
+//   4: d <= max_d <= CLQ_MAX_D   5: larger (generic path)
 __global__ void k_clique_bin(GraphView g, int K, int max_d, int64_t lo, int64_t hi, int32_t *lists,
                              int64_t list_stride, unsigned long long *counts) {
     int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,10 +407,10 @@ __global__ void k_clique_bin(GraphView g, int K, int max_d, int64_t lo, int64_t 
     if (i < hi) {
         v = (int32_t)(g.n - 1 - i);
         int64_t d = g.off[0][v + 1] - g.mid[0][v];
-        if (d >= K - 1) cls = d > max_d ? 4 : d <= 64 ? 0 : d <= 256 ? 1 : d <= 1024 ? 2 : 3;
+        if (d >= K - 1) cls = d > max_d ? 5 : d <= 64 ? 0 : d <= 256 ? 1 : d <= 512 ? 2 : d <= 1024 ? 3 : 4;
     }
     int lane = lane_id();
-    for (int c = 0; c < 5; ++c) {
+    for (int c = 0; c < CLQ_CLASSES; ++c) {
         unsigned long long mask = __ballot(cls == c);
         if (!mask) continue;
         unsigned long long base = 0;
@@ -439,14 +440,14 @@ __global__ void k_chunk_classes(GraphView g, int K, int max_d, int64_t lo, int64
     int32_t v = (int32_t)(g.n - 1 - i);
     int64_t d = g.off[0][v + 1] - g.mid[0][v];
     if (d < K - 1) return;
-    int cls = d > max_d ? 4 : d <= 64 ? 0 : d <= 256 ? 1 : d <= 1024 ? 2 : 3;
+    int cls = d > max_d ? 5 : d <= 64 ? 0 : d <= 256 ? 1 : d <= 512 ? 2 : d <= 1024 ? 3 : 4;
     int a = 0, b = nchunks;  // last chunk whose first root is <= i
     while (b - a > 1) {
         int m = (a + b) >> 1;
         if (bounds[m] <= i) a = m;
         else b = m;
     }
-    atomicAdd(table + a * 5 + cls, 1u);
+    atomicAdd(table + a * 6 + cls, 1u);
 }
 
 struct u32x4 {
@@ -717,4 +718,242 @@ __global__ void k_sum_slots(const unsigned long long *slots, int n, unsigned lon
     for (int i = threadIdx.x; i < n; i += blockDim.x) s += slots[i];
     s = wave_sum_u64(s);
     if (lane_id() == 0 && s) atomicAdd(out, s);
+}
+
+// ---------------------------------------------------------------------------
+// 4-cliques of large universes (256 < d <= 2048): rows built into HBM by
+// many small workgroups, then counted from LDS tiles
+// ---------------------------------------------------------------------------
+//
+// A root with a large N+ is too much for one workgroup: its d rows are built
+// by d/64 workgroups at full occupancy (they only need U and its hash in LDS)
+// and written to a per-root region of a rows buffer in HBM; the count then
+// runs as (root, tile pair, segment) tasks.  Columns are cut into tiles of
+// 1024 bits.  A task holds the rows j of one row tile, restricted to one
+// column tile, in LDS (at most 128 KiB), walks a segment of the rows i, and
+// adds |row_i ^ row_j| over that column tile for every j of the row tile set
+// in row_i.  With two tiles A (first 1024 positions) and B the pairs are
+// (A,A), (A,B) and (B,B): every 4-clique (root, i < j < l) falls in exactly
+// one of them by where j and l lie.
+//
+// Rows buffer, per root (32-bit words): d <= 1024: rows[i][W0], W0 = words of
+// d bits rounded up to 4.  d > 1024: tile 0 rows[i][32] for i < 1024, then at
+// word 1024*32 tile 1 rows[i][W1] for every i, W1 = words of d-1024 bits
+// rounded up to 4.
+
+struct BigLayout {
+    int d, W0, W1;
+    int t1_off;  // word offset of tile 1 inside the root's region
+};
+
+__device__ __forceinline__ BigLayout big_layout(int d) {
+    BigLayout b;
+    b.d = d;
+    if (d <= 1024) {
+        b.W0 = (((d + 31) >> 5) + 3) & ~3;
+        b.W1 = 0;
+        b.t1_off = 0;
+    } else {
+        b.W0 = 32;
+        b.W1 = (((d - 1024 + 31) >> 5) + 3) & ~3;
+        b.t1_off = 1024 * 32;
+    }
+    return b;
+}
+
+#define BIG_ROWS_PER_WG 64
+
+// grid = nroots * (dcap / 64) workgroups of 256 threads; workgroup (ri, rb)
+// builds rows [64*rb, 64*rb + 64) of root ri.  LDS (words): U[dcap] | Dp[dcap]
+// | hash[2*dcap] | stage[4][64].  K == 3 only counts the bits (triangles).
+template <int K>
+__global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
+                                                   int probe_bias, uint32_t *rows_buf, int64_t stride_words,
+                                                   unsigned long long *n_matches, unsigned long long *alg_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
+    const int RB = dcap / BIG_ROWS_PER_WG;
+    const int64_t ri = blockIdx.x / RB;
+    const int i0 = (int)(blockIdx.x % RB) * BIG_ROWS_PER_WG;
+    if (ri >= nroots) return;
+    const int64_t *off = g.off[0], *mid = g.mid[0];
+    const int32_t *adj = g.adj[0];
+    const int32_t u = roots[ri];
+    const int64_t ub = mid[u];
+    const int d = (int)(off[u + 1] - ub);
+    if (i0 >= d) return;
+    int32_t *U = (int32_t *)smem;
+    uint32_t *Dp = smem + dcap;
+    uint32_t *htab = smem + 2 * dcap;
+    uint32_t *stage = smem + 4 * dcap + wave * 64;
+    const BigLayout lay = big_layout(d);
+    uint32_t *region = rows_buf + ri * stride_words;
+
+    int hbits = 1;
+    while ((1 << hbits) < 2 * d) ++hbits;
+    const uint32_t hmask = (1u << hbits) - 1;
+    const int hshift = 32 - hbits;
+    for (int i = tid; i <= (int)hmask; i += 256) htab[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < d; i += 256) {
+        int32_t v = adj[ub + i];
+        U[i] = v;
+        Dp[i] = (uint32_t)(off[v + 1] - mid[v]);
+        clq_hash_insert(htab, hmask, hshift, v, i);
+    }
+    __syncthreads();
+
+    const int Wall = lay.W1 ? 32 + lay.W1 : lay.W0;  // words of a whole row in the stage
+    uint64_t bytes = 0, tri = 0;
+    const int i_end = min(d, i0 + BIG_ROWS_PER_WG);
+    for (int i = i0 + wave; i < i_end; i += 4) {
+        const int32_t v = U[i];
+        const uint64_t per_arc = 12ull + 4ull * ((uint64_t)d + Dp[i]);
+        if (v >= g.hub_base && (int64_t)Dp[i] * 16 >= (int64_t)probe_bias * (int64_t)(d - 1 - i)) {
+            const uint32_t *hrow = g.hub + (size_t)(v - g.hub_base) * (size_t)g.hub_wpr;
+            for (int j0 = 0; j0 < Wall * 32; j0 += 4 * GPM_WAVE) {
+                uint32_t word[4], sh[4];
+                bool live[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = j0 + k * GPM_WAVE + lane;
+                    live[k] = j > i && j < d;
+                    word[k] = 0;
+                    sh[k] = 0;
+                    if (live[k]) {
+                        uint32_t c = (uint32_t)(U[j] - g.hub_base);
+                        word[k] = hrow[c >> 5];
+                        sh[k] = c & 31;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int jb = j0 + k * GPM_WAVE;
+                    if (jb >= Wall * 32) break;
+                    const bool bit = live[k] && ((word[k] >> sh[k]) & 1u);
+                    unsigned long long mask = __ballot(bit);
+                    if (K >= 4 && bit) bytes += per_arc + 4ull * Dp[jb + lane];
+                    if (K == 3) tri += bit;
+                    if (lane == 0) {
+                        stage[jb >> 5] = (uint32_t)mask;
+                        stage[(jb >> 5) + 1] = (uint32_t)(mask >> 32);
+                    }
+                }
+            }
+        } else {
+            stage[lane] = 0;
+            wave_lds_sync();
+            const int64_t vb = mid[v], ve = off[v + 1];
+            for (int64_t p = vb + lane; p < ve; p += GPM_WAVE) {
+                int j = clq_hash_find(htab, hmask, hshift, U, adj[p]);
+                if (j >= 0) {
+                    atomicOr(stage + (j >> 5), 1u << (j & 31));
+                    if (K >= 4) bytes += per_arc + 4ull * Dp[j];
+                    if (K == 3) tri += 1;
+                }
+            }
+        }
+        if (K != 3) {
+            wave_lds_sync();
+            if (lay.W1 == 0) {
+                if (lane < lay.W0) region[(size_t)i * lay.W0 + lane] = stage[lane];
+            } else {
+                if (i < 1024 && lane < 32) region[(size_t)i * 32 + lane] = stage[lane];
+                if (lane < lay.W1) region[(size_t)lay.t1_off + (size_t)i * lay.W1 + lane] = stage[32 + lane];
+            }
+        }
+        wave_lds_sync();
+    }
+    // merge-model bytes: level 2 of the rows built here, level 1 once per root
+    for (int i = i0 + tid; i < i_end; i += 256) bytes += 8ull + 4ull * ((uint64_t)d + Dp[i]);
+    if (i0 == 0 && tid == 0) bytes += 4ull + 4ull * (uint64_t)d;
+    bytes = wave_sum_u64(bytes);
+    tri = wave_sum_u64(tri);
+    if (lane == 0) {
+        if (bytes) atomicAdd(alg_bytes + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)bytes);
+        if (K == 3 && tri) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)tri);
+    }
+}
+
+// grid = nroots * phases * SEG workgroups of 512 threads (phases = 1 for
+// dcap <= 1024, else 3).  LDS (words): J[8][512] (16-bit entries) | tile rows.
+template <int SEG>
+__global__ __launch_bounds__(512) void k_clq_count4(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
+                                                    const uint32_t *rows_buf, int64_t stride_words,
+                                                    unsigned long long *n_matches) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    constexpr int NW = 8;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
+    const int phases = dcap > 1024 ? 3 : 1;
+    const int64_t ri = blockIdx.x / (phases * SEG);
+    const int ph = (int)(blockIdx.x / SEG) % phases;
+    const int seg = (int)(blockIdx.x % SEG);
+    if (ri >= nroots) return;
+    const int32_t u = roots[ri];
+    const int d = (int)(g.off[0][u + 1] - g.mid[0][u]);
+    const BigLayout lay = big_layout(d);
+    if (lay.W1 == 0 && ph > 0) return;
+    const uint32_t *region = rows_buf + ri * stride_words;
+
+    // what this task holds in LDS and walks
+    int j_lo, j_hi, Wt, i_hi;       // rows j of the row tile, words per row of the column tile, rows i walked
+    const uint32_t *tile_rows;      // rows j_lo.. of the column tile, Wt words each
+    const uint32_t *jsrc;           // row i's words over the row tile's positions (list of j)
+    int Wj;
+    const uint32_t *xsrc;           // row i's words over the column tile
+    if (lay.W1 == 0) {
+        j_lo = 0, j_hi = d, Wt = lay.W0, i_hi = d;
+        tile_rows = jsrc = xsrc = region;
+        Wj = lay.W0;
+    } else if (ph == 0) {           // j, l in tile 0
+        j_lo = 0, j_hi = 1024, Wt = 32, i_hi = 1024;
+        tile_rows = jsrc = xsrc = region;
+        Wj = 32;
+    } else if (ph == 1) {           // j in tile 0, l in tile 1
+        j_lo = 0, j_hi = 1024, Wt = lay.W1, i_hi = 1024;
+        tile_rows = xsrc = region + lay.t1_off;
+        jsrc = region;
+        Wj = 32;
+    } else {                        // j, l in tile 1
+        j_lo = 1024, j_hi = d, Wt = lay.W1, i_hi = d;
+        tile_rows = region + lay.t1_off + (size_t)1024 * lay.W1;
+        jsrc = xsrc = region + lay.t1_off;
+        Wj = lay.W1;
+    }
+    uint16_t *J = (uint16_t *)smem + wave * 1024;
+    uint32_t *tile = smem + NW * 512;
+    {
+        const int nvec = (j_hi - j_lo) * Wt / 4;
+        const uint4 *src = reinterpret_cast<const uint4 *>(tile_rows);
+        uint4 *dst = reinterpret_cast<uint4 *>(tile);
+        for (int k = tid; k < nvec; k += 512) dst[k] = src[k];
+    }
+    __syncthreads();
+
+    const int lg = Wt <= 4 ? 0 : Wt <= 8 ? 1 : Wt <= 16 ? 2 : Wt <= 32 ? 3 : 4;
+    const int L = 1 << lg, G = GPM_WAVE >> lg, sub = lane & (L - 1);
+    const bool lane_ok = 4 * sub < Wt;
+    uint64_t total = 0;
+    for (int i = seg * NW + wave; i < i_hi; i += SEG * NW) {
+        const int cnt = clq_expand(jsrc + (size_t)i * Wj, Wj, J, lane);
+        wave_lds_sync();
+        if (cnt && lane_ok) {
+            const u32x4 C = load4(xsrc + (size_t)i * Wt + 4 * sub);
+            const uint32_t *base = tile + 4 * sub;
+            uint32_t acc = 0;
+            int t = lane >> lg;
+            for (; t + 3 * G < cnt; t += 4 * G) {
+                u32x4 r0 = load4(base + (size_t)J[t] * Wt);
+                u32x4 r1 = load4(base + (size_t)J[t + G] * Wt);
+                u32x4 r2 = load4(base + (size_t)J[t + 2 * G] * Wt);
+                u32x4 r3 = load4(base + (size_t)J[t + 3 * G] * Wt);
+                acc += popc4(and4(C, r0)) + popc4(and4(C, r1)) + popc4(and4(C, r2)) + popc4(and4(C, r3));
+            }
+            for (; t < cnt; t += G) acc += popc4(and4(C, load4(base + (size_t)J[t] * Wt)));
+            total += acc;
+        }
+        wave_lds_sync();
+    }
+    total = wave_sum_u64(total);
+    if (lane == 0 && total) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)total);
 }
