@@ -515,6 +515,21 @@ __device__ __forceinline__ int clq_expand(const uint32_t *words, int Wp, uint16_
     return cnt;
 }
 
+// Same for a bitmap held in registers, lane l holding word l (Wp <= 64).
+__device__ __forceinline__ int clq_expand_reg(uint32_t mine, int Wp, uint16_t *J, int lane) {
+    int cnt = 0;
+    for (int w0 = 0; w0 < Wp; w0 += 2) {
+        uint32_t lo = __builtin_amdgcn_readlane(mine, w0), hi = __builtin_amdgcn_readlane(mine, w0 + 1);
+        if ((lo | hi) == 0) continue;  // same for the whole wave
+        uint32_t word = lane < 32 ? lo : hi;
+        bool bit = (word >> (lane & 31)) & 1u;
+        unsigned long long mask = __ballot(bit);
+        if (bit) J[cnt + __popcll(mask & ((1ull << lane) - 1))] = (uint16_t)((w0 << 5) + lane);
+        cnt += __popcll(mask);
+    }
+    return cnt;
+}
+
 // Ways to complete a clique with R more vertices out of the candidate set C.
 // C is held 4 words per lane by lanes 0..L-1 and replicated in every group of
 // L lanes.  Returns a per-lane partial sum (each completed clique is counted
@@ -934,11 +949,26 @@ __global__ __launch_bounds__(512) void k_clq_count4(GraphView g, const int32_t *
     const int L = 1 << lg, G = GPM_WAVE >> lg, sub = lane & (L - 1);
     const bool lane_ok = 4 * sub < Wt;
     uint64_t total = 0;
-    for (int i = seg * NW + wave; i < i_hi; i += SEG * NW) {
-        const int cnt = clq_expand(jsrc + (size_t)i * Wj, Wj, J, lane);
+    const int step = SEG * NW;
+    int i = seg * NW + wave;
+    // row i's list words (lane l holds word l) and its column-tile words, fetched one row ahead
+    uint32_t mine = 0;
+    u32x4 C = {0u, 0u, 0u, 0u};
+    if (i < i_hi) {
+        if (lane < Wj) mine = jsrc[(size_t)i * Wj + lane];
+        if (lane_ok) C = load4(xsrc + (size_t)i * Wt + 4 * sub);
+    }
+    while (i < i_hi) {
+        const int inext = i + step;
+        uint32_t mine_n = 0;
+        u32x4 C_n = {0u, 0u, 0u, 0u};
+        if (inext < i_hi) {
+            if (lane < Wj) mine_n = jsrc[(size_t)inext * Wj + lane];
+            if (lane_ok) C_n = load4(xsrc + (size_t)inext * Wt + 4 * sub);
+        }
+        const int cnt = clq_expand_reg(mine, Wj, J, lane);
         wave_lds_sync();
         if (cnt && lane_ok) {
-            const u32x4 C = load4(xsrc + (size_t)i * Wt + 4 * sub);
             const uint32_t *base = tile + 4 * sub;
             uint32_t acc = 0;
             int t = lane >> lg;
@@ -953,6 +983,9 @@ __global__ __launch_bounds__(512) void k_clq_count4(GraphView g, const int32_t *
             total += acc;
         }
         wave_lds_sync();
+        mine = mine_n;
+        C = C_n;
+        i = inext;
     }
     total = wave_sum_u64(total);
     if (lane == 0 && total) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)total);
