@@ -16,7 +16,7 @@ all: $(LIBDIR)/libgpm_hip.so $(LIBDIR)/libgpm_host.so gpm-par.exe
 
 $(LIBDIR)/libgpm_hip.so: mpi_amd/csrc/gpm_hip.hip mpi_amd/csrc/gpm_kernels.hpp mpi_amd/csrc/gpm_device.hpp include/gpm_hip.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ mpi_amd/csrc/gpm_hip.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ mpi_amd/csrc/gpm_hip.hip -ldl -lpthread
 
 $(LIBDIR)/libgpm_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
+#include <dlfcn.h>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -156,7 +158,54 @@ struct gpm_ctx {
     int workers_live = 0;
     std::atomic<bool> stop{false};
     gpm_stats stats{};
+    std::vector<void *> comms;  // one RCCL communicator per GPU (several GPUs, or GPM_FORCE_RCCL=1)
 };
+
+// ---------------------------------------------------------------------------
+// RCCL, bound at run time: only a context that drives several GPUs needs it
+// ---------------------------------------------------------------------------
+//
+// The per-GPU match counts of one context are summed with one ncclAllReduce
+// over xGMI (the reference gathers results with one MPI message per match,
+// reference: src/gpm-par.c:181, :608-621).  The library is opened with dlopen
+// so that single-GPU users carry no RCCL dependency.
+
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm,
+                     hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok() const { return lib != nullptr; }
+};
+enum { RCCL_SUM = 0, RCCL_UINT64 = 5 };  // ncclSum, ncclUint64 (rccl.h)
+
+static Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void *lib = nullptr;
+        for (const char *n : names)
+            if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) return;
+        Rccl t;
+        t.CommInitAll = (decltype(t.CommInitAll))dlsym(lib, "ncclCommInitAll");
+        t.CommDestroy = (decltype(t.CommDestroy))dlsym(lib, "ncclCommDestroy");
+        t.AllReduce = (decltype(t.AllReduce))dlsym(lib, "ncclAllReduce");
+        t.GroupStart = (decltype(t.GroupStart))dlsym(lib, "ncclGroupStart");
+        t.GroupEnd = (decltype(t.GroupEnd))dlsym(lib, "ncclGroupEnd");
+        t.GetErrorString = (decltype(t.GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (t.CommInitAll && t.CommDestroy && t.AllReduce && t.GroupStart && t.GroupEnd && t.GetErrorString) {
+            t.lib = lib;
+            r = t;
+        }
+    });
+    return r;
+}
 
 static int64_t env_i64(const char *name, int64_t dflt) {
     const char *v = getenv(name);
@@ -236,6 +285,8 @@ static void free_buffers(DevState &d) {
 
 extern "C" void gpm_hip_destroy(gpm_ctx *ctx) {
     if (!ctx) return;
+    for (void *c : ctx->comms)
+        if (c) (void)rccl().CommDestroy(c);
     for (auto &d : ctx->devs) {
         (void)hipSetDevice(d.dev);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
@@ -291,6 +342,22 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->chunk_hint = env_i64("GPM_CHUNKS", 0);
     ctx->use_tail = env_i64("GPM_NO_TAIL", 0) == 0;
     ctx->use_clique = env_i64("GPM_NO_CLIQUE", 0) == 0;
+    if (ngpus > 1 || env_i64("GPM_FORCE_RCCL", 0)) {
+        if (!rccl().ok()) {
+            gpm_hip_destroy(ctx);
+            return fail(GPM_ENODEV, "a multi-GPU context needs librccl.so, which could not be loaded");
+        }
+        std::vector<int> devlist;
+        for (auto &d : ctx->devs) devlist.push_back(d.dev);
+        ctx->comms.assign((size_t)ngpus, nullptr);
+        int rc = rccl().CommInitAll(ctx->comms.data(), ngpus, devlist.data());
+        if (rc != 0) {
+            std::string why = rccl().GetErrorString(rc);
+            ctx->comms.clear();
+            gpm_hip_destroy(ctx);
+            return fail(GPM_ENODEV, "ncclCommInitAll failed: %s", why.c_str());
+        }
+    }
     *out = ctx;
     return GPM_OK;
 }
@@ -1295,6 +1362,44 @@ extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, v
         for (auto &d : ctx->devs)
             if (d.rc && rc == GPM_OK) rc = fail(d.rc, "%s", d.err.c_str());
     }
+    // Sum the per-GPU counts: one all-reduce of a 64-bit word over RCCL when the
+    // context has communicators, so that every GPU (and the host, from GPU 0)
+    // holds the total.
+    uint64_t reduced = 0;
+    bool have_reduced = false;
+    if (rc == GPM_OK && !ctx->comms.empty()) {
+        const Rccl &R = rccl();
+        int nrc = 0;
+        for (auto &d : ctx->devs) {
+            (void)hipSetDevice(d.dev);
+            d.ctr_host[CTR_CLQ_CLASS0] = d.canonical;
+            (void)hipMemcpyAsync(d.ctr + CTR_CLQ_CLASS0, d.ctr_host + CTR_CLQ_CLASS0, sizeof(unsigned long long),
+                                 hipMemcpyHostToDevice, d.stream);
+        }
+        nrc = R.GroupStart();
+        for (size_t i = 0; i < ctx->devs.size() && nrc == 0; ++i) {
+            DevState &d = ctx->devs[i];
+            (void)hipSetDevice(d.dev);
+            nrc = R.AllReduce(d.ctr + CTR_CLQ_CLASS0, d.ctr + CTR_CLQ_CLASS0 + 1, 1, RCCL_UINT64, RCCL_SUM,
+                              ctx->comms[i], d.stream);
+        }
+        if (nrc == 0) nrc = R.GroupEnd();
+        if (nrc != 0) {
+            rc = fail(GPM_ERUNTIME, "RCCL all-reduce of the counts failed: %s", R.GetErrorString(nrc));
+        } else {
+            DevState &d0 = ctx->devs[0];
+            (void)hipSetDevice(d0.dev);
+            hipError_t e = hipMemcpyAsync(d0.ctr_host + CTR_CLQ_CLASS0 + 1, d0.ctr + CTR_CLQ_CLASS0 + 1,
+                                          sizeof(unsigned long long), hipMemcpyDeviceToHost, d0.stream);
+            for (auto &d : ctx->devs) {
+                (void)hipSetDevice(d.dev);
+                if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
+            }
+            if (e != hipSuccess) rc = fail(GPM_ERUNTIME, "reading the reduced count failed: %s", hipGetErrorString(e));
+            reduced = d0.ctr_host[CTR_CLQ_CLASS0 + 1];
+            have_reduced = rc == GPM_OK;
+        }
+    }
     gpm_stats &st = ctx->stats;
     memset(&st, 0, sizeof st);
     for (size_t i = 0; i < ctx->devs.size(); ++i) {
@@ -1308,6 +1413,11 @@ extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, v
         st.extend_launches += d.extend_launches;
         for (int k = 0; k < GPM_MAXP; ++k) st.rows_in[k] += d.rows_in[k];
         st.chunks[i] = d.chunks;
+    }
+    if (have_reduced) {
+        if (reduced != st.canonical) rc = fail(GPM_ERUNTIME, "RCCL sum %llu differs from the host sum %llu",
+                                               (unsigned long long)reduced, (unsigned long long)st.canonical);
+        st.canonical = reduced;
     }
     st.matches = st.canonical * ctx->plan.n_aut;
     st.ms_total =

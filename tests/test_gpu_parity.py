@@ -230,6 +230,37 @@ def test_clique_kernel_equals_generic_path(monkeypatch):
         assert counts[0] == counts[1] == counts[2], (pname, counts)
 
 
+def test_counts_are_reduced_over_rccl(monkeypatch):
+    """The multi-GPU context path (RCCL communicators, all-reduce of the counts) on one GPU."""
+    monkeypatch.setenv("GPM_FORCE_RCCL", "1")
+    spec = next(g for g in GOLDEN if g["name"] == "rmat10_clique4")
+    n, s, d = util.build_graph(spec)
+    m = binding.Matcher(1)
+    upload(m, n, s, d)
+    for pname, want in (("clique4", spec["count"]),):
+        m.set_pattern(gen.PATTERNS[pname])
+        assert m.findMatches(count_only=True) == want
+        rows = m.findMatches(count_only=False)
+        assert len(rows) == want
+    m.close()
+
+
+def test_chunk_count_does_not_change_the_result():
+    n, s, d = util.build_graph({"graph": "rmat", "scale": 12, "ef": 8, "seed": 1})
+    m = binding.Matcher(1)
+    upload(m, n, s, d)
+    for pname in ("clique4", "cycle4"):
+        m.set_pattern(gen.PATTERNS[pname])
+        counts = []
+        for chunks in (0, 1, 7, 500):
+            m.set_chunks(chunks)
+            counts.append(m.findMatches(count_only=True))
+            st = m.stats()
+            assert st.chunks[0] >= 1
+        assert len(set(counts)) == 1, (pname, counts)
+    m.close()
+
+
 def test_bad_arguments_are_rejected():
     m = binding.Matcher(1)
     off = np.array([0, 2, 1], dtype=np.int64)  # not monotone
