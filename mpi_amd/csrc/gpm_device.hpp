@@ -24,6 +24,11 @@ struct GraphView {
     int32_t hub_base;       // n when there is no hub matrix
     int32_t hub_wpr;        // 32-bit words per row
     const uint32_t *hub;
+    // labcnt[v * nlab + l] = neighbours of v that carry label l (symmetric
+    // labelled graphs only, else nullptr): lets a leaf level be counted
+    // without walking the list.
+    int32_t nlab;
+    const uint32_t *labcnt;
 };
 
 __device__ __forceinline__ bool hub_arc(const GraphView &g, int32_t from, int32_t to) {
@@ -149,6 +154,21 @@ __device__ __forceinline__ uint64_t level_bytes(const GraphView &g, const LevelP
         bytes += 4ull * (uint64_t)(e - b);
     }
     return bytes;
+}
+
+// Number of candidates of a leaf level -- one whose only requirement besides
+// the label is adjacency to its source vertex s -- for a partial match m[0..k)
+// on a simple symmetric graph: the (label-matching) neighbours of s that are
+// not already in the match.  No list is walked.
+__device__ __forceinline__ int64_t leaf_count(const GraphView &g, const LevelPlan &lv, const int32_t *m, int k,
+                                              int32_t s) {
+    int64_t c = lv.label >= 0 ? (int64_t)g.labcnt[(size_t)s * (size_t)g.nlab + (size_t)lv.label]
+                              : g.off[0][s + 1] - g.off[0][s];
+    for (int t = 0; t < k; ++t) {
+        const int32_t x = m[t];
+        if (x != s && (lv.label < 0 || g.label[x] == (uint8_t)lv.label) && in_list(g, 0, PART_FULL, s, x)) c -= 1;
+    }
+    return c;
 }
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {

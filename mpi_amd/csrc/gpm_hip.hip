@@ -101,6 +101,7 @@ struct DevState {
     int32_t *perm = nullptr;
     uint8_t *label = nullptr;
     uint32_t *hub = nullptr;
+    uint32_t *labcnt = nullptr;
     GraphView gv{};
     // search buffers
     int64_t cap_rows = 0, cap_emit = 0;
@@ -248,6 +249,8 @@ static void free_graph(DevState &d) {
     dev_free(d.perm);
     dev_free(d.label);
     dev_free(d.hub);
+    dev_free(d.labcnt);
+    d.labcnt = nullptr;
     d.perm = nullptr;
     d.label = nullptr;
     d.hub = nullptr;
@@ -537,6 +540,24 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(s));
     }
+
+    // per-vertex label histograms of the neighbours (symmetric labelled graphs)
+    d.gv.nlab = 0;
+    d.gv.labcnt = nullptr;
+    if (labels && !in_off && n > 0) {
+        int nlab = 0;
+        for (int32_t v = 0; v < n; ++v) nlab = std::max(nlab, (int)labels[v] + 1);
+        const size_t bytes = (size_t)n * (size_t)nlab * sizeof(uint32_t);
+        if (bytes <= ((size_t)2 << 30)) {
+            HIP_TRY(hipMalloc(&d.labcnt, bytes));
+            HIP_TRY(hipMemsetAsync(d.labcnt, 0, bytes, s));
+            d.gv.nlab = nlab;
+            k_label_counts<<<grid_for(n), 256, 0, s>>>(d.gv, d.labcnt);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));
+            d.gv.labcnt = d.labcnt;
+        }
+    }
     return GPM_OK;
 }
 
@@ -704,6 +725,17 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
         ti.b_upper_is_a = lt[L + 1][L];
         ti.reuse = ctx->info.simple && n_extra >= 1 && n_extra <= 2 && same_list_set(la, lb_rest) && same_bounds &&
                    same_filters && env_i64("GPM_NO_REUSE", 0) == 0;
+        // leaf levels: adjacency to the source is the only requirement besides the label
+        const bool closed_ok = ctx->info.simple && ctx->info.symmetric && env_i64("GPM_NO_LEAF", 0) == 0;
+        auto leaf = [&](const LevelPlan &X) {
+            return X.n_cons == 0 && X.n_lower == 0 && X.n_upper == 0 && X.min_out <= 1 && X.min_in <= 1 &&
+                   (X.label < 0 || ctx->devs[0].gv.labcnt != nullptr);
+        };
+        ti.leaf_b = closed_ok && leaf(B);
+        const bool same_set = A.src_level == B.src_level && A.label == B.label;
+        const bool disjoint = A.label >= 0 && B.label >= 0 && A.label != B.label;
+        ti.leaf_pair = closed_ok && leaf(A) && leaf(B) && B.src_level != L && (same_set || disjoint);
+        ti.pair_same_set = same_set;
     }
     // K-clique under a total order: every level's operand lists are the lists of
     // all earlier levels, each vertex is bounded below by its predecessor, and
@@ -915,6 +947,14 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
     d.rows_in[k - 1] += (uint64_t)nrows;
     const int32_t *rows = d.F[k - 1];
 
+    if (a.count_only && ctx->use_tail && k == P - 2 && ctx->ti.leaf_pair) {
+        int rc = timed_begin(d, 0, nrows);
+        if (rc) return rc;
+        k_leaf_pair<<<grid_for(nrows), 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, rows, nrows, d.ctr + CTR_TAIL_MATCHES,
+                                                    d.ctr + CTR_TAIL_BYTES);
+        HIP_TRY(hipGetLastError());
+        return timed_end(d);
+    }
     if (a.count_only && ctx->use_tail && k == P - 2) {
         unsigned blocks = (unsigned)std::min<int64_t>((nrows + TAIL_WAVES - 1) / TAIL_WAVES, 16384);
         int rc = timed_begin(d, 0, nrows);

@@ -219,6 +219,9 @@ struct TailInfo {
     int8_t b_lower_is_a;    // B requires c > a (a is B's largest lower bound)
     int8_t b_upper_is_a;    // B requires c < a
     int8_t any_shortest;    // simple graph: level A may walk its shortest list
+    int8_t leaf_b;          // level B is a leaf level: counted in closed form per A survivor
+    int8_t leaf_pair;       // levels A and B are both leaves off earlier vertices: closed form per row
+    int8_t pair_same_set;   // ... and draw from the same candidate set (same source, same label)
 };
 
 // Count |{c in staged[sb, se) : c in every extra list of a, c != a}|, where
@@ -324,6 +327,21 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
             bool last = i0 + GPM_WAVE >= e;
             if (!last && (reuse_row || n_staged + GPM_WAVE <= TAIL_CAP)) continue;
             wave_lds_sync();
+            if (ti.leaf_b && !reuse_row) {
+                // level B is a leaf: one lane per survivor a, nothing is walked
+                for (int ia = lane; ia < n_staged; ia += GPM_WAVE) {
+                    const int32_t a = staged[ia];
+                    const int32_t s = lb.src_level == L ? a : m[lb.src_level];
+                    int64_t c = leaf_count(g, lb, m, L, s);
+                    if (a != s && (lb.label < 0 || g.label[a] == (uint8_t)lb.label) && in_list(g, 0, PART_FULL, s, a))
+                        c -= 1;
+                    if (c > 0) cnt += (uint64_t)c;
+                    bytes += 4ull * (uint64_t)(L + 1) + 4ull * (uint64_t)(g.off[0][s + 1] - g.off[0][s]);
+                }
+                n_staged = 0;
+                wave_lds_sync();
+                continue;
+            }
             // level B for every staged survivor a
             for (int ia = 0; ia < n_staged; ++ia) {
                 int32_t a = staged[ia];
@@ -354,6 +372,41 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
         if (cnt) atomicAdd(n_matches, (unsigned long long)cnt);
         if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
     }
+}
+
+// Last two levels when both are leaf levels hanging off earlier vertices: one
+// thread per partial match, candidates counted in closed form: |A| * |B| minus
+// the pairs that would bind the same vertex twice.
+__global__ void k_leaf_pair(GraphView g, PlanView pl, TailInfo ti, const int32_t *rows, int64_t nrows,
+                            unsigned long long *n_matches, unsigned long long *alg_bytes) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int L = pl.P - 2;
+    uint64_t cnt = 0, bytes = 0;
+    if (r < nrows) {
+        const int32_t *m = rows + r * L;
+        const LevelPlan &la = pl.lv[L], &lb = pl.lv[L + 1];
+        const int32_t sa = m[la.src_level], sb = m[lb.src_level];
+        const int64_t ca = leaf_count(g, la, m, L, sa), cb = leaf_count(g, lb, m, L, sb);
+        if (ca > 0 && cb > 0) cnt = (uint64_t)(ca * cb - (ti.pair_same_set ? ca : 0));
+        const uint64_t la_len = (uint64_t)(g.off[0][sa + 1] - g.off[0][sa]);
+        const uint64_t lb_len = (uint64_t)(g.off[0][sb + 1] - g.off[0][sb]);
+        bytes = 4ull * (uint64_t)L + 4ull * la_len;
+        if (ca > 0) bytes += (uint64_t)ca * (4ull * (uint64_t)(L + 1) + 4ull * lb_len);
+    }
+    cnt = wave_sum_u64(cnt);
+    bytes = wave_sum_u64(bytes);
+    if (lane_id() == 0) {
+        if (cnt) atomicAdd(n_matches, (unsigned long long)cnt);
+        if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
+    }
+}
+
+// Neighbours per label of every vertex (thread per vertex).
+__global__ void k_label_counts(GraphView g, uint32_t *labcnt) {
+    int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n) return;
+    uint32_t *row = labcnt + (size_t)v * (size_t)g.nlab;
+    for (int64_t i = g.off[0][v]; i < g.off[0][v + 1]; ++i) row[g.label[g.adj[0][i]]] += 1;
 }
 
 // ---------------------------------------------------------------------------

@@ -163,6 +163,8 @@ PATTERNS = {
     "tri_dir": (3, [(1, 2), (2, 3), (3, 1)]),
     "triangle": (3, _both([(1, 2), (2, 3), (1, 3)])),
     "path3": (3, _both([(1, 2), (2, 3)])),
+    "star4": (4, _both([(1, 2), (1, 3), (1, 4)])),
+    "path4": (4, _both([(1, 2), (2, 3), (3, 4)])),
     "cycle4": (4, _both([(1, 2), (2, 3), (3, 4), (4, 1)])),
     "clique4": (4, _both([(a, b) for a in range(1, 5) for b in range(a + 1, 5)])),
     "diamond": (4, _both([(1, 2), (1, 3), (2, 3), (2, 4), (3, 4)])),

@@ -230,6 +230,30 @@ def test_clique_kernel_equals_generic_path(monkeypatch):
         assert counts[0] == counts[1] == counts[2], (pname, counts)
 
 
+@pytest.mark.parametrize("pname", ["path3", "star4", "path4", "tree5", "house", "diamond"])
+@pytest.mark.parametrize("symbreak", [True, False])
+@pytest.mark.parametrize("labelled", [False, True])
+def test_leaf_levels_counted_in_closed_form(pname, symbreak, labelled, monkeypatch):
+    """Patterns that end in leaf vertices: the closed-form counts equal the oracle's enumeration
+    and the count obtained with the closed forms switched off."""
+    n, s, d = util.build_graph({"graph": "plaw", "n": 512, "avg_deg": 6, "seed": 3})
+    P = gen.PATTERNS[pname][0]
+    dl = pl = None
+    if labelled:
+        dl = gen.vertex_labels(n, 3, seed=7).numpy().astype(np.int32)
+        pl = [(i * 2) % 3 for i in range(P)]
+    want, _, _ = util.oracle_matches(n, s, d, gen.PATTERNS[pname], data_labels=dl, pattern_labels=pl, want_rows=False)
+    got = []
+    for leaf_off in ("0", "1"):
+        monkeypatch.setenv("GPM_NO_LEAF", leaf_off)
+        m = binding.Matcher(1)
+        upload(m, n, s, d, labels=dl)
+        m.set_pattern(gen.PATTERNS[pname], labels=pl, symbreak=symbreak)
+        got.append(m.findMatches(count_only=True))
+        m.close()
+    assert got == [want, want]
+
+
 def test_counts_are_reduced_over_rccl(monkeypatch):
     """The multi-GPU context path (RCCL communicators, all-reduce of the counts) on one GPU."""
     monkeypatch.setenv("GPM_FORCE_RCCL", "1")

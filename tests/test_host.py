@@ -122,7 +122,7 @@ def test_disconnected_pattern_is_rejected():
     binding.host_lib().freePattern(p)
 
 
-N_AUT = {"edge": 1, "edge_und": 2, "tri_dir": 3, "triangle": 6, "path3": 2, "cycle4": 8, "clique4": 24,
+N_AUT = {"edge": 1, "edge_und": 2, "tri_dir": 3, "triangle": 6, "path3": 2, "star4": 6, "path4": 2, "cycle4": 8, "clique4": 24,
          "diamond": 4, "k4_dag": 1, "rev4": 1, "tree5": 2, "tree5_dir": 1, "clique5": 120, "clique6": 720, "house": 2,
          "k6_minus_pm": 48, "k6_minus_e": 48}
 
