@@ -7,6 +7,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -118,6 +119,14 @@ struct DevState {
     int64_t clq_stride = 0;
     int clq_scratch_blocks = 0;
     unsigned long long *clq_slots = nullptr;  // [0,CLQ_SLOTS) matches, [CLQ_SLOTS,2*CLQ_SLOTS) bytes
+    // 4-cycle path: two-path count of every root, counter arrays (slab 0 for heavy roots, one per
+    // workgroup of the light kernel), root queues of the light kernel's launches
+    int64_t *cyc_cost = nullptr;
+    int64_t *cyc_wp = nullptr;  // two-paths of all arcs before arc p (m + 1 entries)
+    uint32_t *cyc_dense = nullptr;
+    int64_t cyc_stride = 0;
+    int cyc_blocks = 0;
+    unsigned long long *cyc_queue = nullptr;
     std::vector<EventPair> events;
     size_t events_used = 0;
     // results of the last search
@@ -145,6 +154,11 @@ struct gpm_ctx {
     bool use_tail = true;
     int clique_k = 0;  // K when the plan is a K-clique under a total ordering, else 0
     bool use_clique = true;
+    bool cycle4 = false;  // the plan is the 4-cycle with all 8 automorphisms folded
+    bool use_cycle4 = true;
+    int64_t cyc_heavy_thr = 0;             // two-paths above which a root gets the whole GPU
+    std::vector<int64_t> cyc_heavy_roots;  // root indices at or above the threshold, ascending
+    std::vector<int64_t> cyc_heavy_paths;  // their two-path counts
     int64_t chunk_roots = 1 << 20;  // upper bound of a chunk's size
     int64_t chunk_hint = 0;         // how many chunks to aim for (0 = 32 per GPU of the context)
     std::vector<Chunk> chunks;
@@ -213,6 +227,22 @@ static int64_t env_i64(const char *name, int64_t dflt) {
     return (v && *v) ? atoll(v) : dflt;
 }
 
+static double now_seconds() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// GPM_PROGRESS=<seconds>: a line on stderr at most that often while a long search runs.
+static void progress_tick(int dev, uint64_t chunk, size_t n_chunks, int level, int64_t rows) {
+    static const int64_t every = env_i64("GPM_PROGRESS", 0);
+    static std::atomic<double> last{0.0};
+    if (every <= 0) return;
+    const double t = now_seconds();
+    if (t - last.load() < (double)every) return;
+    last.store(t);
+    fprintf(stderr, "gpm progress: device %d chunk %llu of %zu, level %d, %lld partial matches in hand\n", dev,
+            (unsigned long long)chunk, n_chunks, level, (long long)rows);
+}
+
 extern "C" int gpm_hip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -250,6 +280,14 @@ static void free_graph(DevState &d) {
     dev_free(d.label);
     dev_free(d.hub);
     dev_free(d.labcnt);
+    dev_free(d.cyc_cost);
+    dev_free(d.cyc_wp);
+    d.cyc_wp = nullptr;
+    dev_free(d.cyc_dense);
+    dev_free(d.cyc_queue);
+    d.cyc_cost = nullptr;
+    d.cyc_dense = nullptr;
+    d.cyc_queue = nullptr;
     d.labcnt = nullptr;
     d.perm = nullptr;
     d.label = nullptr;
@@ -345,6 +383,8 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->chunk_hint = env_i64("GPM_CHUNKS", 0);
     ctx->use_tail = env_i64("GPM_NO_TAIL", 0) == 0;
     ctx->use_clique = env_i64("GPM_NO_CLIQUE", 0) == 0;
+    ctx->use_cycle4 = env_i64("GPM_NO_CYCLE4", 0) == 0;
+    ctx->cyc_heavy_thr = std::max<int64_t>(1, env_i64("GPM_CYCLE4_HEAVY", (int64_t)1 << 21));
     if (ngpus > 1 || env_i64("GPM_FORCE_RCCL", 0)) {
         if (!rccl().ok()) {
             gpm_hip_destroy(ctx);
@@ -725,6 +765,8 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
         ti.b_upper_is_a = lt[L + 1][L];
         ti.reuse = ctx->info.simple && n_extra >= 1 && n_extra <= 2 && same_list_set(la, lb_rest) && same_bounds &&
                    same_filters && env_i64("GPM_NO_REUSE", 0) == 0;
+        ti.twin = ctx->info.simple && n_extra == 0 && same_list_set(la, lb_rest) && same_bounds && same_filters &&
+                  env_i64("GPM_NO_TWIN", 0) == 0;
         // leaf levels: adjacency to the source is the only requirement besides the label
         const bool closed_ok = ctx->info.simple && ctx->info.symmetric && env_i64("GPM_NO_LEAF", 0) == 0;
         auto leaf = [&](const LevelPlan &X) {
@@ -752,6 +794,20 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
         }
         clique = clique && pv.lv[0].label < 0;
         if (clique) ctx->clique_k = P;
+    }
+    // The 4-cycle with its 8 automorphisms folded by ordering bounds, no labels:
+    // four pattern edges, every vertex on two of them.
+    ctx->cycle4 = false;
+    if (P == 4 && ctx->info.simple && ctx->info.symmetric && p->n_aut == 8) {
+        int deg[4] = {0, 0, 0, 0}, edges = 0;
+        bool plain = pv.lv[0].label < 0;
+        for (int k = 1; k < P; ++k) {
+            const LevelPlan &lv = pv.lv[k];
+            plain = plain && lv.label < 0;
+            deg[lv.src_level]++, deg[k]++, edges++;
+            for (int j = 0; j < lv.n_cons; ++j) deg[lv.cons_level[j]]++, deg[k]++, edges++;
+        }
+        ctx->cycle4 = plain && edges == 4 && deg[0] == 2 && deg[1] == 2 && deg[2] == 2 && deg[3] == 2;
     }
     ctx->have_plan = true;
     return GPM_OK;
@@ -946,6 +1002,7 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
     if (nrows == 0 || ctx->stop) return GPM_OK;
     d.rows_in[k - 1] += (uint64_t)nrows;
     const int32_t *rows = d.F[k - 1];
+    progress_tick(d.dev, d.chunks, ctx->chunks.size(), k, nrows);
 
     if (a.count_only && ctx->use_tail && k == P - 2 && ctx->ti.leaf_pair) {
         int rc = timed_begin(d, 0, nrows);
@@ -1183,6 +1240,43 @@ static int clique_chunk(const SearchArgs &a, DevState &d, ChunkSlot &sl, const C
     return rc;
 }
 
+// Buffers of the 4-cycle path on one device: the two-path prefix over the arcs,
+// the two-path count of every root, the counter arrays and the root queues.
+static int ensure_cycle4(gpm_ctx *ctx, DevState &d) {
+    if (d.cyc_cost) return GPM_OK;
+    HIP_TRY(hipSetDevice(d.dev));
+    hipStream_t s = d.stream;
+    const int64_t n = ctx->info.n, m = d.m[0];
+    d.cyc_stride = (n + 63) / 64 * 64 + 64;
+    const int64_t budget = env_i64("GPM_CYCLE4_MEM_GB", 32) << 30;
+    d.cyc_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(64, budget / (4 * d.cyc_stride) - CYC_HEAVY_SLABS));
+    const size_t dense_bytes = ((size_t)d.cyc_blocks + CYC_HEAVY_SLABS) * (size_t)d.cyc_stride * sizeof(uint32_t);
+    HIP_TRY(hipMalloc(&d.cyc_cost, ((size_t)n + 1) * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&d.cyc_wp, ((size_t)m + 2) * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&d.cyc_dense, dense_bytes));
+    HIP_TRY(hipMalloc(&d.cyc_queue, 1024 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d.cyc_dense, 0, dense_bytes, s));
+    HIP_TRY(hipMemsetAsync(d.cyc_wp, 0, sizeof(int64_t), s));
+    if (m > 0) {
+        int64_t *len = nullptr;
+        void *tmp = nullptr;
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipMalloc(&len, (size_t)m * sizeof(int64_t)));
+        k_cycle4_arc_paths<<<grid_for(m), 256, 0, s>>>(d.gv, m, len);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, len, d.cyc_wp + 1, (size_t)m, rocprim::plus<int64_t>(), s));
+        HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+        HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, len, d.cyc_wp + 1, (size_t)m, rocprim::plus<int64_t>(), s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipFree(tmp));
+        HIP_TRY(hipFree(len));
+    }
+    if (n > 0) k_cycle4_cost<<<grid_for(n), 256, 0, s>>>(d.gv, d.cyc_wp, n, d.cyc_cost);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return GPM_OK;
+}
+
 // Cut the root range into chunks of similar estimated cost (heaviest roots
 // first, so early chunks are short), capped at chunk_roots roots each.  Every
 // context over the same graph, plan, root range and hint builds the same table,
@@ -1200,10 +1294,17 @@ static int prepare_chunks(gpm_ctx *ctx) {
     const int P = ctx->pv.P;
     const bool oriented = P > 1 && ctx->pv.lv[1].src_part == PART_ABOVE;
     const int min_d = ctx->clique_k && ctx->use_clique ? ctx->clique_k - 1 : 0;
+    const bool cyc = ctx->cycle4 && ctx->use_cycle4;
     int64_t *cost = nullptr, *pref = nullptr;
     HIP_TRY(hipMalloc(&cost, (size_t)nroots * sizeof(int64_t)));
     HIP_TRY(hipMalloc(&pref, (size_t)nroots * sizeof(int64_t)));
-    k_root_cost<<<grid_for(nroots), 256, 0, s>>>(d.gv, oriented, min_d, lo, hi, cost);
+    if (cyc) {
+        int rc = ensure_cycle4(ctx, d);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(cost, d.cyc_cost + lo, (size_t)nroots * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    } else {
+        k_root_cost<<<grid_for(nroots), 256, 0, s>>>(d.gv, oriented, min_d, lo, hi, cost);
+    }
     size_t tmp_bytes = 0;
     void *tmp = nullptr;
     HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, cost, pref, (size_t)nroots, rocprim::plus<int64_t>(), s));
@@ -1215,6 +1316,16 @@ static int prepare_chunks(gpm_ctx *ctx) {
     HIP_TRY(hipFree(tmp));
     HIP_TRY(hipFree(cost));
     HIP_TRY(hipFree(pref));
+    ctx->cyc_heavy_roots.clear();
+    ctx->cyc_heavy_paths.clear();
+    if (cyc)
+        for (int64_t i = 0; i < nroots; ++i) {
+            const int64_t paths = hpref[(size_t)i] - (i ? hpref[(size_t)i - 1] : 0) - 1;
+            if (paths >= ctx->cyc_heavy_thr) {
+                ctx->cyc_heavy_roots.push_back(lo + i);
+                ctx->cyc_heavy_paths.push_back(paths);
+            }
+        }
     const int64_t want = ctx->chunk_hint > 0 ? ctx->chunk_hint : 32 * (int64_t)ctx->devs.size();
     const int64_t target = std::max<int64_t>(1, hpref.back() / want);
     int64_t begin = 0;
@@ -1275,13 +1386,61 @@ static int device_search(const SearchArgs &a, DevState &d) {
     const bool clique = a.count_only && ctx->clique_k >= 3 && ctx->use_clique;
     if (clique) HIP_TRY(hipMemsetAsync(d.clq_slots, 0, 2 * CLQ_SLOTS * sizeof(unsigned long long), s));
     HIP_TRY(hipStreamSynchronize(s));  // counters are zero before any slot stream adds to them
-    uint64_t seq = 0;
+    const bool cyc = a.count_only && ctx->cycle4 && ctx->use_cycle4;
+    if (cyc) {
+        if ((rc = ensure_cycle4(ctx, d))) return rc;
+        HIP_TRY(hipMemsetAsync(d.cyc_queue, 0, 1024 * sizeof(unsigned long long), s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    uint64_t seq = 0, cyc_heavy_seq = 0;
     while (!ctx->stop) {
         const uint64_t c = claim_chunk(ctx);
         if (c >= ctx->chunks.size()) break;
         const Chunk &ch = ctx->chunks[(size_t)c];
         const int64_t lo = ch.lo, hi = ch.hi;
         d.chunks++;
+        if (cyc) {
+            // light roots of the chunk: one launch on the first slot stream (launches share the
+            // workgroups' counter arrays, so they run one after the other); heavy roots: one launch
+            // and one memset each, spread over CYC_HEAVY_SLABS streams with one counter array each
+            hipStream_t ls = d.slots[0].stream;
+            if (seq && seq % 1024 == 0) {
+                HIP_TRY(hipStreamSynchronize(ls));
+                HIP_TRY(hipMemsetAsync(d.cyc_queue, 0, 1024 * sizeof(unsigned long long), ls));
+            }
+            d.rows_in[0] += (uint64_t)(hi - lo);
+            if ((rc = timed_begin(d, 0, hi - lo, ls))) return rc;
+            k_cycle4_light<<<(unsigned)d.cyc_blocks, 256, 0, ls>>>(d.gv, d.cyc_wp, lo, hi, d.cyc_cost,
+                                                                  ctx->cyc_heavy_thr, d.cyc_queue + seq % 1024,
+                                                                  d.cyc_dense, d.cyc_stride, d.ctr + CTR_TAIL_MATCHES,
+                                                                  d.ctr + CTR_TAIL_BYTES);
+            HIP_TRY(hipGetLastError());
+            if ((rc = timed_end(d, ls))) return rc;
+            seq++;
+            const auto &hv = ctx->cyc_heavy_roots;
+            for (size_t h = (size_t)(std::lower_bound(hv.begin(), hv.end(), lo) - hv.begin()); h < hv.size() && hv[h] < hi;
+                 ++h) {
+                const int32_t v1 = (int32_t)(ctx->info.n - 1 - hv[h]);
+                const int slab = (int)(cyc_heavy_seq++ % CYC_HEAVY_SLABS);
+                hipStream_t hs = slab == 0 ? s : d.slots[slab].stream;
+                uint32_t *cnt = d.cyc_dense + (size_t)slab * (size_t)d.cyc_stride;
+                const int64_t nblk = (ctx->cyc_heavy_paths[h] + CYC_BLOCK - 1) / CYC_BLOCK;
+                const unsigned grid = (unsigned)std::min<int64_t>(1024, (nblk + 3) / 4);
+                if ((rc = timed_begin(d, 0, 1, hs))) return rc;
+                k_cycle4_heavy<<<grid, 256, 0, hs>>>(d.gv, d.cyc_wp, v1, cnt, d.ctr + CTR_TAIL_MATCHES,
+                                                     d.ctr + CTR_TAIL_BYTES);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)v1 * sizeof(uint32_t), hs));
+                if ((rc = timed_end(d, hs))) return rc;
+                progress_tick(d.dev, d.chunks, ctx->chunks.size(), 0, hv[h]);
+                if (d.events_used > 4096) {
+                    for (auto &x : d.slots) HIP_TRY(hipStreamSynchronize(x.stream));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    if ((rc = collect_times(d))) return rc;
+                }
+            }
+            continue;
+        }
         if (clique) {
             ChunkSlot &sl = d.slots[seq++ % CLQ_INFLIGHT];
             if (sl.busy) {  // at most CLQ_INFLIGHT chunks ahead of the GPU
@@ -1328,6 +1487,8 @@ static int device_search(const SearchArgs &a, DevState &d) {
             if (rc) return rc;
         }
     }
+    if (cyc)
+        for (auto &x : d.slots) HIP_TRY(hipStreamSynchronize(x.stream));
     if (clique) {
         for (auto &x : d.slots) {
             HIP_TRY(hipStreamSynchronize(x.stream));

@@ -222,6 +222,8 @@ struct TailInfo {
     int8_t leaf_b;          // level B is a leaf level: counted in closed form per A survivor
     int8_t leaf_pair;       // levels A and B are both leaves off earlier vertices: closed form per row
     int8_t pair_same_set;   // ... and draw from the same candidate set (same source, same label)
+    int8_t twin;            // level B has exactly level A's lists, bounds and filters and no list of the A
+                            // vertex: the two draw from one survivor set S, counted as pairs of S
 };
 
 // Count |{c in staged[sb, se) : c in every extra list of a, c != a}|, where
@@ -310,6 +312,22 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
             }
         }
         const int32_t *wadj = g.adj[walk < 0 ? la.src_dir : la.cons_dir[walk]];
+        if (ti.twin) {
+            // levels A and B are twins: |S| survivors give |S|(|S|-1) ordered pairs, or
+            // half of that when an ordering bound ties B to A; nothing is staged
+            uint32_t s_cnt = 0;
+            for (int64_t i = b + lane; i < e; i += GPM_WAVE) {
+                const int32_t c = wadj[i];
+                s_cnt += c > lo_id && c < hi_id && accept(g, la, m, L, c, walk);
+            }
+            const uint64_t s_all = wave_sum_u64(s_cnt);
+            if (lane == 0) {
+                const uint64_t pairs = s_all * (s_all - (s_all ? 1 : 0));
+                cnt += (ti.b_lower_is_a || ti.b_upper_is_a) ? pairs / 2 : pairs;
+                bytes += s_all * (4ull + level_bytes(g, la, m, L));  // level B per survivor: one more id, same lists
+            }
+            continue;
+        }
         const bool reuse_row = ti.reuse && (e - b) <= TAIL_CAP;
 
         int n_staged = 0;
@@ -1042,4 +1060,189 @@ __global__ __launch_bounds__(512) void k_clq_count4(GraphView g, const int32_t *
     }
     total = wave_sum_u64(total);
     if (lane == 0 && total) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)total);
+}
+
+// ---------------------------------------------------------------------------
+// 4-cycles: two-path counting
+// ---------------------------------------------------------------------------
+//
+// On a simple symmetric graph every 4-cycle has one largest vertex v1 (ids are
+// degree ranks, so v1 is its highest-degree vertex) and one vertex v3 opposite
+// to it; the other two, v2 and v4, are common neighbours of v1 and v3 that lie
+// below v1.  With c(v1, v3) = number of two-paths v1 - v2 - v3 whose v2 and v3
+// are both below v1, the cycles with largest vertex v1 number
+// sum over v3 of c(c-1)/2, and each stands for 8 embeddings (the reference
+// reports every automorphic image, reference: src/gpm-par.c:179-243).  Walking
+// only below v1 keeps the two-path count near sum over arcs of the smaller
+// degree, whatever the skew.
+//
+// The counters c(v1, .) live in a dense array of n 32-bit words that the
+// walking workgroups own; atomicAdd returns the old value k and adding up all
+// old values gives sum c(c-1)/2 without a second reading pass.  The array is
+// zero between roots: light roots walk their two-paths again and store zeros,
+// heavy roots (all workgroups on one root) are followed by a memset of [0, v1).
+//
+// Work is balanced whatever the skew: wp[p] is the number of two-paths of all
+// arcs before arc p (prefix sum over the CSR, arcs to a higher vertex count
+// zero), so the two-paths of root v1 are the range [wp[off[v1]], wp[mid[v1]])
+// and a wave takes a block of CYC_BLOCK consecutive two-paths of it, finding
+// the arc it starts in by binary search and then walking tiles of 64 arcs.
+
+#define CYC_BLOCK 8192
+
+// Two-paths of every arc p = (v1 -> v2): the entries of N(v2) below v1 when
+// v2 < v1, else none.  One thread per arc.
+__global__ void k_cycle4_arc_paths(GraphView g, int64_t m, int64_t *len) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const int64_t *off = g.off[0];
+    const int32_t *adj = g.adj[0];
+    int32_t lo = 0, hi = g.n;  // last v with off[v] <= p
+    while (hi - lo > 1) {
+        int32_t mid = lo + ((hi - lo) >> 1);
+        if (off[mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    const int32_t v1 = lo, v2 = adj[p];
+    len[p] = v2 < v1 ? lower_bound_g(adj, off[v2], off[v2 + 1], v1) - off[v2] : 0;
+}
+
+// cost[i] = two-paths of root index i (vertex n-1-i), plus one.
+__global__ void k_cycle4_cost(GraphView g, const int64_t *wp, int64_t nroots, int64_t *cost) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nroots) return;
+    const int32_t v1 = (int32_t)(g.n - 1 - i);
+    cost[i] = wp[g.mid[0][v1]] - wp[g.off[0][v1]] + 1;
+}
+
+// One wave's pass over blocks blk0, blk0 + bstep, ... of the two-paths of root
+// v1.  RESET = false: count, returns the sum of the old counter values;
+// RESET = true: store zeros.  s_pre / s_beg are this wave's 64-entry LDS arrays.
+template <bool RESET>
+__device__ __forceinline__ uint64_t cyc_wave_pass(const GraphView &g, const int64_t *wp, int32_t v1, int64_t blk0,
+                                                  int64_t bstep, uint32_t *cnt, uint32_t *s_pre, int64_t *s_beg) {
+    const int lane = lane_id();
+    const int64_t *off = g.off[0];
+    const int32_t *adj = g.adj[0];
+    const int64_t lb = off[v1], le = g.mid[0][v1];
+    const int64_t base = wp[lb], W = wp[le] - base;
+    const int64_t nblk = (W + CYC_BLOCK - 1) / CYC_BLOCK;
+    uint64_t acc = 0;
+    for (int64_t blk = blk0; blk < nblk; blk += bstep) {
+        int64_t w0 = blk * CYC_BLOCK;
+        const int64_t w1 = min(W, w0 + CYC_BLOCK);
+        int64_t a = lb, ae = le;  // last arc a in [lb, le) with wp[a] - base <= w0
+        while (ae - a > 1) {
+            int64_t mid = a + ((ae - a) >> 1);
+            if (wp[mid] - base <= w0) a = mid;
+            else ae = mid;
+        }
+        while (w0 < w1) {
+            // tile of the 64 arcs from a on: their two-paths are [t0, t1)
+            const int64_t q = a + lane;
+            const int64_t t0 = wp[a] - base;
+            const int64_t qe = min(le, a + GPM_WAVE);
+            const int64_t t1 = wp[qe] - base;
+            uint32_t pre = 0xffffffffu;
+            int64_t beg = 0;
+            if (q < qe) {
+                pre = (uint32_t)(wp[q] - base - t0);
+                beg = off[adj[q]];
+            }
+            wave_lds_sync();
+            s_pre[lane] = pre;
+            s_beg[lane] = beg;
+            wave_lds_sync();
+            const int64_t wend = min(w1, t1);
+            for (int64_t wq = w0; wq < wend; wq += 4 * GPM_WAVE) {
+                int32_t v3[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t w = wq + u * GPM_WAVE + lane;
+                    v3[u] = -1;
+                    if (w < wend) {
+                        const uint32_t r = (uint32_t)(w - t0);
+                        int j = 0;  // last entry with s_pre[j] <= r
+#pragma unroll
+                        for (int st = GPM_WAVE / 2; st > 0; st >>= 1)
+                            if (s_pre[j + st] <= r) j += st;
+                        v3[u] = adj[s_beg[j] + (r - s_pre[j])];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (v3[u] < 0) continue;
+                    if (RESET) cnt[v3[u]] = 0;
+                    else acc += atomicAdd(cnt + v3[u], 1u);
+                }
+            }
+            w0 = wend;
+            a = qe;
+        }
+    }
+    return acc;
+}
+
+// Light roots: one workgroup of 4 waves per root, roots taken from a queue
+// (index order = heaviest first); workgroup b owns the counter array
+// dense + (CYC_HEAVY_SLABS + b) * stride.  Roots whose cost exceeds heavy_thr
+// are left to k_cycle4_heavy.
+#define CYC_HEAVY_SLABS 4
+__global__ __launch_bounds__(256) void k_cycle4_light(GraphView g, const int64_t *wp, int64_t lo, int64_t hi,
+                                                      const int64_t *cost, int64_t heavy_thr,
+                                                      unsigned long long *queue, uint32_t *dense, int64_t stride,
+                                                      unsigned long long *n_cycles, unsigned long long *alg_bytes) {
+    __shared__ uint32_t s_pre[4][GPM_WAVE];
+    __shared__ int64_t s_beg[4][GPM_WAVE];
+    __shared__ long long s_next;
+    const int wave = threadIdx.x / GPM_WAVE, lane = lane_id();
+    uint32_t *cnt = dense + (size_t)(blockIdx.x + CYC_HEAVY_SLABS) * (size_t)stride;
+    uint64_t acc = 0, bytes = 0;
+    for (;;) {
+        __threadfence();  // the zeros of the last root are in place before the next root counts
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = (long long)(lo + (int64_t)atomicAdd(queue, 1ull));
+        __syncthreads();
+        const int64_t i = s_next;
+        if (i >= hi) break;
+        const int64_t paths = cost[i] - 1;
+        if (paths >= heavy_thr || paths < 2) continue;  // a cycle needs two two-paths
+        const int32_t v1 = (int32_t)(g.n - 1 - i);
+        acc += cyc_wave_pass<false>(g, wp, v1, wave, 4, cnt, s_pre[wave], s_beg[wave]);
+        // bytes of this root: its list and one prefix per arc, every two-path read and counted
+        if (threadIdx.x == 0) bytes += 8ull * (uint64_t)paths + 4ull + 12ull * (uint64_t)(g.mid[0][v1] - g.off[0][v1]);
+        __threadfence();
+        __syncthreads();
+        if (paths * 8 >= (int64_t)v1) {  // zero [0, v1) with coalesced stores
+            uint4 *z = reinterpret_cast<uint4 *>(cnt);
+            for (int x = threadIdx.x; x < (v1 + 3) / 4; x += 256) z[x] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            cyc_wave_pass<true>(g, wp, v1, wave, 4, cnt, s_pre[wave], s_beg[wave]);
+        }
+    }
+    acc = wave_sum_u64(acc);
+    bytes = wave_sum_u64(bytes);
+    if (lane == 0) {
+        if (acc) atomicAdd(n_cycles, (unsigned long long)acc);
+        if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
+    }
+}
+
+// Heavy root: the whole grid walks one root into counter array `cnt`; the
+// caller zeroes cnt[0, v1) afterwards.
+__global__ __launch_bounds__(256) void k_cycle4_heavy(GraphView g, const int64_t *wp, int32_t v1, uint32_t *cnt,
+                                                      unsigned long long *n_cycles, unsigned long long *alg_bytes) {
+    __shared__ uint32_t s_pre[4][GPM_WAVE];
+    __shared__ int64_t s_beg[4][GPM_WAVE];
+    const int wave = threadIdx.x / GPM_WAVE, lane = lane_id();
+    uint64_t acc = cyc_wave_pass<false>(g, wp, v1, (int64_t)blockIdx.x * 4 + wave, (int64_t)gridDim.x * 4, cnt,
+                                        s_pre[wave], s_beg[wave]);
+    uint64_t bytes = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t lb = g.off[0][v1], le = g.mid[0][v1];
+        bytes = 8ull * (uint64_t)(wp[le] - wp[lb]) + 4ull + 12ull * (uint64_t)(le - lb);
+    }
+    acc = wave_sum_u64(acc);
+    if (lane == 0 && acc) atomicAdd(n_cycles, (unsigned long long)acc);
+    if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
 }

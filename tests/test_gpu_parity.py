@@ -111,10 +111,12 @@ VARIANTS = [
     {"symbreak": True, "env": {"GPM_NO_CLIQUE": "1"}},
     {"symbreak": True, "env": {"GPM_CLIQUE_MAX_D": "6"}},
     {"symbreak": True, "env": {"GPM_NO_CLIQUE": "1", "GPM_NO_REUSE": "1"}},
+    {"symbreak": True, "env": {"GPM_NO_TWIN": "1", "GPM_NO_CYCLE4": "1"}},
 ]
 VAR_SPECS = [g for g in GOLDEN if g["name"] in (
     "rand9_sym_clique4", "rand9_sym_cycle4", "rand9_dir_tree5_dir", "rand40_dir_rev4", "rand40_dir_k4_dag",
     "rmat8_triangle", "rmat8_clique4", "rmat8_cycle4", "rmat8_house", "rmat8_clique5", "skew8_k6_minus_e",
+    "skew9_k6_minus_pm", "rmat10_cycle4",
     "plaw9_tree5_labelled4", "er10k_triangle")]
 
 
@@ -228,6 +230,37 @@ def test_clique_kernel_equals_generic_path(monkeypatch):
             counts.append(m.findMatches(count_only=True))
             m.close()
         assert counts[0] == counts[1] == counts[2], (pname, counts)
+
+
+@pytest.mark.parametrize("env", [{}, {"GPM_HUB_ROWS": "0"}, {"GPM_HUB_ROWS": "512"},
+                                 {"GPM_CLIQUE_PROBE_BIAS": "1000000"}],
+                         ids=["hubs", "no_hub_matrix", "few_hubs", "lists_only"])
+def test_large_universes_of_the_clique_kernel(env, monkeypatch):
+    """Dense random graph whose roots have |N+| up to ~1500: every size class of the bitmap
+    kernels (one wave, LDS rows, rows built into HBM with one or two column tiles), with the
+    rows built from the hub matrix, from hashed list walks, or a mix, against the
+    level-by-level path."""
+    n = 2000
+    s, d = util.rand_digraph(n, 3, 4, 11, True)
+    counts = {}
+    for pname in ("triangle", "clique4"):
+        for k in ("GPM_NO_CLIQUE", "GPM_HUB_ROWS", "GPM_CLIQUE_PROBE_BIAS"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("GPM_NO_CLIQUE", "1")
+        m = binding.Matcher(1)
+        upload(m, n, s, d)
+        m.set_pattern(gen.PATTERNS[pname])
+        want = m.findMatches(count_only=True)
+        m.close()
+        monkeypatch.delenv("GPM_NO_CLIQUE")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = binding.Matcher(1)
+        upload(m, n, s, d)
+        m.set_pattern(gen.PATTERNS[pname])
+        counts[pname] = (m.findMatches(count_only=True), want)
+        m.close()
+    assert all(a == b for a, b in counts.values()), counts
 
 
 @pytest.mark.parametrize("pname", ["path3", "star4", "path4", "tree5", "house", "diamond"])
