@@ -100,6 +100,17 @@ typedef struct {
     int32_t has_labels;
 } gpm_graph_info;
 
+/* Kernel families the search is made of; indices of the kernel_* arrays of gpm_stats. */
+#define GPM_KERNEL_KINDS 8
+enum {
+    GPM_KIND_TAIL = 0,      /* fused last two levels: list intersection through LDS, closed-form leaves */
+    GPM_KIND_EXTEND = 1,    /* level-by-level extension with ballot / prefix-sum compaction */
+    GPM_KIND_CLIQUE = 2,    /* cliques, small universes: bitmap rows built and counted in LDS */
+    GPM_KIND_CLQ_BUILD = 3, /* cliques, large universes: bitmap rows built into HBM */
+    GPM_KIND_CLQ_COUNT = 4, /* cliques, large universes: rows counted from LDS tiles */
+    GPM_KIND_CYCLE4 = 5     /* 4-cycles: two-path counters */
+};
+
 typedef struct {
     uint64_t matches;                      /* embeddings (all automorphic images) */
     uint64_t canonical;                    /* matches before multiplying by n_aut */
@@ -111,6 +122,10 @@ typedef struct {
     double   ms_extend_kernel;             /* summed device time of the level-extension kernel */
     uint64_t tail_launches, extend_launches;
     uint64_t chunks[8];                    /* root chunks taken by each GPU of the context */
+    /* per kernel family: summed device time, launches, merge-model bytes of the work done */
+    double   kernel_ms[GPM_KERNEL_KINDS];
+    uint64_t kernel_launches[GPM_KERNEL_KINDS];
+    uint64_t kernel_alg_bytes[GPM_KERNEL_KINDS];
 } gpm_stats;
 
 /* Row sink: called on the calling host thread with `nrows` complete matches,
@@ -170,6 +185,9 @@ int gpm_hip_set_roots(gpm_ctx *ctx, int64_t lo, int64_t hi);
 int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, void *user, uint64_t *total);
 
 int gpm_hip_stats(const gpm_ctx *ctx, gpm_stats *stats);
+
+/* Name of kernel family `kind` (GPM_KIND_*), "" when out of range. */
+const char *gpm_hip_kernel_name(int kind);
 
 #ifdef __cplusplus
 }

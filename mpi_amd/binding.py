@@ -15,7 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-MAXP, MAXC = 10, 9
+MAXP, MAXC, KINDS = 10, 9, 8
 
 
 class GpmError(RuntimeError):
@@ -55,7 +55,9 @@ class gpm_stats(ctypes.Structure):
                 ("tail_alg_bytes", ctypes.c_uint64), ("ms_total", ctypes.c_double),
                 ("ms_tail_kernel", ctypes.c_double), ("ms_extend_kernel", ctypes.c_double),
                 ("tail_launches", ctypes.c_uint64), ("extend_launches", ctypes.c_uint64),
-                ("chunks", ctypes.c_uint64 * 8)]
+                ("chunks", ctypes.c_uint64 * 8),
+                ("kernel_ms", ctypes.c_double * KINDS), ("kernel_launches", ctypes.c_uint64 * KINDS),
+                ("kernel_alg_bytes", ctypes.c_uint64 * KINDS)]
 
 
 PLAN_SYMMETRIC_DATA, PLAN_BREAK_SYMMETRY, PLAN_DEGREE_FILTER = 1, 2, 4
@@ -65,7 +67,7 @@ ROW_SINK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes
 # every symbol include/gpm_hip.h declares
 HIP_SYMBOLS = ["gpm_hip_last_error", "gpm_hip_device_count", "gpm_hip_create", "gpm_hip_destroy",
                "gpm_hip_upload_graph", "gpm_hip_graph_info", "gpm_hip_set_plan", "gpm_hip_set_cursor",
-               "gpm_hip_set_roots", "gpm_hip_set_chunks", "gpm_hip_search", "gpm_hip_stats"]
+               "gpm_hip_set_roots", "gpm_hip_set_chunks", "gpm_hip_search", "gpm_hip_stats", "gpm_hip_kernel_name"]
 
 _hip = None
 _host = None
@@ -91,6 +93,8 @@ def hip_lib():
         lib.gpm_hip_search.argtypes = [ctypes.c_void_p, ctypes.c_int, ROW_SINK, ctypes.c_void_p,
                                        ctypes.POINTER(ctypes.c_uint64)]
         lib.gpm_hip_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(gpm_stats)]
+        lib.gpm_hip_kernel_name.restype = ctypes.c_char_p
+        lib.gpm_hip_kernel_name.argtypes = [ctypes.c_int]
         _hip = lib
     return _hip
 

@@ -60,15 +60,20 @@ enum {  // slots of the per-device counter block (unsigned long long each)
     CTR_TAIL_MATCHES = 18,
     CTR_TAIL_BYTES = 19,
     CTR_EMIT = 20,
+    CTR_CYC_BYTES = 21,       // merge-model bytes of the 4-cycle kernels
+    CTR_KIND_BYTES = 40,      // [40, 40 + GPM_KERNEL_KINDS): bytes summed out of the clique slots, per kind
     CTR_CLQ_CLASS0 = 24,  // [24, 29): roots per size class of the clique kernel
-    CTR_COUNT = 32
+    CTR_COUNT = 48
 };
 
 struct EventPair {
     hipEvent_t a, b;
-    int kind;  // 0 = tail kernel, 1 = extend kernel
+    int kind;  // GPM_KIND_*
     int64_t rows;
 };
+
+static const char *const kKindNames[GPM_KERNEL_KINDS] = {"k_tail", "k_extend", "k_clique", "k_clq_build",
+                                                         "k_clq_count4", "k_cycle4", "", ""};
 
 // One chunk of the root range; in clique mode also its roots per size class.
 struct Chunk {
@@ -132,8 +137,8 @@ struct DevState {
     // results of the last search
     uint64_t canonical = 0, alg_bytes = 0, tail_bytes = 0, chunks = 0;
     uint64_t rows_in[GPM_MAXP] = {};
-    double ms_tail = 0, ms_extend = 0;
-    uint64_t tail_launches = 0, extend_launches = 0;
+    double ms_kind[GPM_KERNEL_KINDS] = {};
+    uint64_t launches_kind[GPM_KERNEL_KINDS] = {}, bytes_kind[GPM_KERNEL_KINDS] = {};
     int rc = 0;
     std::string err;
 };
@@ -890,7 +895,7 @@ static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
         for (auto &sl : d.slots)
             HIP_TRY(hipMalloc(&sl.scratch,
                               (size_t)d.clq_scratch_blocks * (size_t)CLQ_MAX_D * (CLQ_MAX_D / 32) * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&d.clq_slots, 2 * CLQ_SLOTS * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&d.clq_slots, GPM_KERNEL_KINDS * CLQ_SLOTS * sizeof(unsigned long long)));
     }
     if (want_emit > d.cap_emit) {
         dev_free(d.emit);
@@ -938,15 +943,10 @@ static int collect_times(DevState &d) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d.events[i].a, d.events[i].b));
         if (getenv("GPM_TRACE"))
-            fprintf(stderr, "gpm trace: %s rows %lld ms %.3f\n", d.events[i].kind == 0 ? "tail" : "extend",
+            fprintf(stderr, "gpm trace: %s rows %lld ms %.3f\n", kKindNames[d.events[i].kind],
                     (long long)d.events[i].rows, ms);
-        if (d.events[i].kind == 0) {
-            d.ms_tail += ms;
-            d.tail_launches++;
-        } else {
-            d.ms_extend += ms;
-            d.extend_launches++;
-        }
+        d.ms_kind[d.events[i].kind] += ms;
+        d.launches_kind[d.events[i].kind]++;
     }
     d.events_used = 0;
     return GPM_OK;
@@ -1005,7 +1005,7 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
     progress_tick(d.dev, d.chunks, ctx->chunks.size(), k, nrows);
 
     if (a.count_only && ctx->use_tail && k == P - 2 && ctx->ti.leaf_pair) {
-        int rc = timed_begin(d, 0, nrows);
+        int rc = timed_begin(d, GPM_KIND_TAIL, nrows);
         if (rc) return rc;
         k_leaf_pair<<<grid_for(nrows), 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, rows, nrows, d.ctr + CTR_TAIL_MATCHES,
                                                     d.ctr + CTR_TAIL_BYTES);
@@ -1014,7 +1014,7 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
     }
     if (a.count_only && ctx->use_tail && k == P - 2) {
         unsigned blocks = (unsigned)std::min<int64_t>((nrows + TAIL_WAVES - 1) / TAIL_WAVES, 16384);
-        int rc = timed_begin(d, 0, nrows);
+        int rc = timed_begin(d, GPM_KIND_TAIL, nrows);
         if (rc) return rc;
         k_tail<<<blocks, TAIL_WAVES * GPM_WAVE, 0, s>>>(d.gv, ctx->pv, ctx->ti, rows, nrows, d.ctr + CTR_TAIL_MATCHES,
                                                         d.ctr + CTR_TAIL_BYTES);
@@ -1050,7 +1050,7 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
         }
         if (gcount > 0) {
             const int64_t g1 = g0 + gcount;
-            int rc = timed_begin(d, 1);
+            int rc = timed_begin(d, GPM_KIND_EXTEND);
             if (rc) return rc;
             if (terminal && a.count_only) {
                 k_extend<MODE_COUNT><<<grid_for(gcount), 256, 0, s>>>(d.gv, ctx->pv, k, rows, d.pref[k - 1],
@@ -1116,7 +1116,8 @@ template <int K>
 static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[6], int bias) {
     static_assert(K == 3 || K == 4, "build/count pair exists for triangles and 4-cliques");
     hipStream_t s = sl.stream;
-    unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + CLQ_SLOTS;
+    unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + (size_t)GPM_KIND_CLQ_BUILD * CLQ_SLOTS;
+    unsigned long long *byt3 = d.clq_slots + (size_t)GPM_KIND_CLQ_COUNT * CLQ_SLOTS;  // level 3, done by the count kernel
     const int dcaps[3] = {512, 1024, 2048};
     const int64_t strides[3] = {512 * 16, 1024 * 32, 1024 * 32 + 2048 * 32};
     constexpr int SEG = 4;
@@ -1133,15 +1134,15 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[6], in
         const int phases = dcap > 1024 ? 3 : 1;
         for (int64_t b0 = 0; b0 < (int64_t)n[c]; b0 += batch) {
             const int64_t nb = std::min<int64_t>(batch, (int64_t)n[c] - b0);
-            if ((rc = timed_begin(d, 0, nb, s))) return rc;
+            if ((rc = timed_begin(d, GPM_KIND_CLQ_BUILD, nb, s))) return rc;
             k_clq_build<K><<<(unsigned)(nb * (dcap / BIG_ROWS_PER_WG)), 256, lds_build, s>>>(
-                d.gv, list + b0, nb, dcap, bias, sl.rows, stride, cnt, byt);
+                d.gv, list + b0, nb, dcap, bias, sl.rows, stride, cnt, byt, byt3);
             HIP_TRY(hipGetLastError());
             if ((rc = timed_end(d, s))) return rc;
             if (K == 4) {
                 HIP_TRY(hipFuncSetAttribute((const void *)k_clq_count4<SEG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_count));
-                if ((rc = timed_begin(d, 0, nb, s))) return rc;
+                if ((rc = timed_begin(d, GPM_KIND_CLQ_COUNT, nb, s))) return rc;
                 k_clq_count4<SEG><<<(unsigned)(nb * phases * SEG), 512, lds_count, s>>>(d.gv, list + b0, nb, dcap,
                                                                                         sl.rows, stride, cnt);
                 HIP_TRY(hipGetLastError());
@@ -1155,7 +1156,7 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[6], in
 template <int K>
 static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[6]) {
     hipStream_t s = sl.stream;
-    unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + CLQ_SLOTS;
+    unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + (size_t)GPM_KIND_CLIQUE * CLQ_SLOTS;
     const int32_t *l = sl.lists;
     const int64_t st = d.clq_stride;
     const int bias = (int)env_i64("GPM_CLIQUE_PROBE_BIAS", 0);
@@ -1165,7 +1166,7 @@ static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[6]) {
     } else {
         if (n[4]) {  // rows in global scratch, persistent workgroups
             unsigned blocks = (unsigned)std::min<uint64_t>(n[4], (uint64_t)d.clq_scratch_blocks);
-            if ((rc = timed_begin(d, 0, (int64_t)n[4], s))) return rc;
+            if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[4], s))) return rc;
             k_clique<K, 256, false><<<blocks, 256, clq_lds_bytes(K, 256, CLQ_MAX_D, false), s>>>(
                 d.gv, l + 4 * st, (int64_t)n[4], CLQ_MAX_D, bias, sl.scratch, cnt, byt);
             HIP_TRY(hipGetLastError());
@@ -1176,7 +1177,7 @@ static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[6]) {
             const size_t lds = clq_lds_bytes(K, 512, 1024, true);
             HIP_TRY(hipFuncSetAttribute((const void *)k_clique<K, 512, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if ((rc = timed_begin(d, 0, (int64_t)n[c], s))) return rc;
+            if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[c], s))) return rc;
             k_clique<K, 512, true><<<(unsigned)n[c], 512, lds, s>>>(d.gv, l + c * st, (int64_t)n[c], 1024, bias,
                                                                     nullptr, cnt, byt);
             HIP_TRY(hipGetLastError());
@@ -1184,14 +1185,14 @@ static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[6]) {
         }
     }
     if (n[1]) {
-        if ((rc = timed_begin(d, 0, (int64_t)n[1], s))) return rc;
+        if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[1], s))) return rc;
         k_clique<K, 256, true><<<(unsigned)n[1], 256, clq_lds_bytes(K, 256, 256, true), s>>>(
             d.gv, l + st, (int64_t)n[1], 256, bias, nullptr, cnt, byt);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d, s))) return rc;
     }
     if (n[0]) {
-        if ((rc = timed_begin(d, 0, (int64_t)n[0], s))) return rc;
+        if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[0], s))) return rc;
         k_clique<K, 64, true><<<(unsigned)n[0], 64, clq_lds_bytes(K, 64, 64, true), s>>>(d.gv, l, (int64_t)n[0], 64, bias,
                                                                                      nullptr, cnt, byt);
         HIP_TRY(hipGetLastError());
@@ -1365,8 +1366,13 @@ static int prepare_chunks(gpm_ctx *ctx) {
 }
 
 static uint64_t claim_chunk(gpm_ctx *ctx) {
-    if (ctx->shared_cursor) return __atomic_fetch_add((uint64_t *)ctx->shared_cursor, 1, __ATOMIC_RELAXED);
-    return ctx->own_cursor.fetch_add(1, std::memory_order_relaxed);
+    // GPM_EMULATE_RANKS=N with GPM_EMULATE_RANK=r: take every N-th chunk starting at r, the share one of
+    // N processes would get from a shared cursor (for sizing chunk counts on a single GPU)
+    static const uint64_t emu_n = (uint64_t)std::max<int64_t>(1, env_i64("GPM_EMULATE_RANKS", 1));
+    static const uint64_t emu_r = (uint64_t)env_i64("GPM_EMULATE_RANK", 0) % emu_n;
+    uint64_t c = ctx->shared_cursor ? __atomic_fetch_add((uint64_t *)ctx->shared_cursor, 1, __ATOMIC_RELAXED)
+                                    : ctx->own_cursor.fetch_add(1, std::memory_order_relaxed);
+    return c * emu_n + emu_r;
 }
 
 static int device_search(const SearchArgs &a, DevState &d) {
@@ -1378,13 +1384,15 @@ static int device_search(const SearchArgs &a, DevState &d) {
     hipStream_t s = d.stream;
     HIP_TRY(hipMemsetAsync(d.ctr, 0, CTR_COUNT * sizeof(unsigned long long), s));
     d.canonical = d.alg_bytes = d.tail_bytes = d.chunks = 0;
-    d.ms_tail = d.ms_extend = 0;
-    d.tail_launches = d.extend_launches = 0;
+    for (int kd = 0; kd < GPM_KERNEL_KINDS; ++kd) {
+        d.ms_kind[kd] = 0;
+        d.launches_kind[kd] = d.bytes_kind[kd] = 0;
+    }
     d.events_used = 0;
     memset(d.rows_in, 0, sizeof d.rows_in);
     uint64_t p1_rows = 0;
     const bool clique = a.count_only && ctx->clique_k >= 3 && ctx->use_clique;
-    if (clique) HIP_TRY(hipMemsetAsync(d.clq_slots, 0, 2 * CLQ_SLOTS * sizeof(unsigned long long), s));
+    if (clique) HIP_TRY(hipMemsetAsync(d.clq_slots, 0, GPM_KERNEL_KINDS * CLQ_SLOTS * sizeof(unsigned long long), s));
     HIP_TRY(hipStreamSynchronize(s));  // counters are zero before any slot stream adds to them
     const bool cyc = a.count_only && ctx->cycle4 && ctx->use_cycle4;
     if (cyc) {
@@ -1409,11 +1417,11 @@ static int device_search(const SearchArgs &a, DevState &d) {
                 HIP_TRY(hipMemsetAsync(d.cyc_queue, 0, 1024 * sizeof(unsigned long long), ls));
             }
             d.rows_in[0] += (uint64_t)(hi - lo);
-            if ((rc = timed_begin(d, 0, hi - lo, ls))) return rc;
+            if ((rc = timed_begin(d, GPM_KIND_CYCLE4, hi - lo, ls))) return rc;
             k_cycle4_light<<<(unsigned)d.cyc_blocks, 256, 0, ls>>>(d.gv, d.cyc_wp, lo, hi, d.cyc_cost,
                                                                   ctx->cyc_heavy_thr, d.cyc_queue + seq % 1024,
                                                                   d.cyc_dense, d.cyc_stride, d.ctr + CTR_TAIL_MATCHES,
-                                                                  d.ctr + CTR_TAIL_BYTES);
+                                                                  d.ctr + CTR_CYC_BYTES);
             HIP_TRY(hipGetLastError());
             if ((rc = timed_end(d, ls))) return rc;
             seq++;
@@ -1426,9 +1434,9 @@ static int device_search(const SearchArgs &a, DevState &d) {
                 uint32_t *cnt = d.cyc_dense + (size_t)slab * (size_t)d.cyc_stride;
                 const int64_t nblk = (ctx->cyc_heavy_paths[h] + CYC_BLOCK - 1) / CYC_BLOCK;
                 const unsigned grid = (unsigned)std::min<int64_t>(1024, (nblk + 3) / 4);
-                if ((rc = timed_begin(d, 0, 1, hs))) return rc;
+                if ((rc = timed_begin(d, GPM_KIND_CYCLE4, 1, hs))) return rc;
                 k_cycle4_heavy<<<grid, 256, 0, hs>>>(d.gv, d.cyc_wp, v1, cnt, d.ctr + CTR_TAIL_MATCHES,
-                                                     d.ctr + CTR_TAIL_BYTES);
+                                                     d.ctr + CTR_CYC_BYTES);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)v1 * sizeof(uint32_t), hs));
                 if ((rc = timed_end(d, hs))) return rc;
@@ -1495,7 +1503,8 @@ static int device_search(const SearchArgs &a, DevState &d) {
             x.busy = false;
         }
         k_sum_slots<<<1, 64, 0, s>>>(d.clq_slots, CLQ_SLOTS, d.ctr + CTR_TAIL_MATCHES);
-        k_sum_slots<<<1, 64, 0, s>>>(d.clq_slots + CLQ_SLOTS, CLQ_SLOTS, d.ctr + CTR_TAIL_BYTES);
+        for (int kd : {GPM_KIND_CLIQUE, GPM_KIND_CLQ_BUILD, GPM_KIND_CLQ_COUNT})
+            k_sum_slots<<<1, 64, 0, s>>>(d.clq_slots + (size_t)kd * CLQ_SLOTS, CLQ_SLOTS, d.ctr + CTR_KIND_BYTES + kd);
     }
     HIP_TRY(hipMemcpyAsync(d.ctr_host, d.ctr, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1503,7 +1512,14 @@ static int device_search(const SearchArgs &a, DevState &d) {
     if (rc) return rc;
     if (a.count_only) d.canonical = d.ctr_host[CTR_MATCHES] + d.ctr_host[CTR_TAIL_MATCHES] + p1_rows;
     else if (P == 1) d.canonical = p1_rows;
-    d.tail_bytes = d.ctr_host[CTR_TAIL_BYTES];
+    d.bytes_kind[GPM_KIND_TAIL] = d.ctr_host[CTR_TAIL_BYTES];
+    d.bytes_kind[GPM_KIND_EXTEND] = d.ctr_host[CTR_BYTES];
+    d.bytes_kind[GPM_KIND_CYCLE4] = d.ctr_host[CTR_CYC_BYTES];
+    for (int kd : {GPM_KIND_CLIQUE, GPM_KIND_CLQ_BUILD, GPM_KIND_CLQ_COUNT})
+        d.bytes_kind[kd] = d.ctr_host[CTR_KIND_BYTES + kd];
+    d.tail_bytes = 0;
+    for (int kd = 0; kd < GPM_KERNEL_KINDS; ++kd)
+        if (kd != GPM_KIND_EXTEND) d.tail_bytes += d.bytes_kind[kd];
     d.alg_bytes = d.ctr_host[CTR_BYTES] + d.tail_bytes + 4ull * d.rows_in[0];
     return GPM_OK;
 }
@@ -1608,10 +1624,18 @@ extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, v
         st.canonical += d.canonical;
         st.alg_bytes += d.alg_bytes;
         st.tail_alg_bytes += d.tail_bytes;
-        st.ms_tail_kernel += d.ms_tail;
-        st.ms_extend_kernel += d.ms_extend;
-        st.tail_launches += d.tail_launches;
-        st.extend_launches += d.extend_launches;
+        for (int kd = 0; kd < GPM_KERNEL_KINDS; ++kd) {
+            st.kernel_ms[kd] += d.ms_kind[kd];
+            st.kernel_launches[kd] += d.launches_kind[kd];
+            st.kernel_alg_bytes[kd] += d.bytes_kind[kd];
+            if (kd == GPM_KIND_EXTEND) {
+                st.ms_extend_kernel += d.ms_kind[kd];
+                st.extend_launches += d.launches_kind[kd];
+            } else {
+                st.ms_tail_kernel += d.ms_kind[kd];
+                st.tail_launches += d.launches_kind[kd];
+            }
+        }
         for (int k = 0; k < GPM_MAXP; ++k) st.rows_in[k] += d.rows_in[k];
         st.chunks[i] = d.chunks;
     }
@@ -1625,6 +1649,10 @@ extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, v
         1e3 * (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
     if (total) *total = st.matches;
     return rc;
+}
+
+extern "C" const char *gpm_hip_kernel_name(int kind) {
+    return kind >= 0 && kind < GPM_KERNEL_KINDS ? kKindNames[kind] : "";
 }
 
 extern "C" int gpm_hip_stats(const gpm_ctx *ctx, gpm_stats *stats) {

@@ -855,7 +855,8 @@ __device__ __forceinline__ BigLayout big_layout(int d) {
 template <int K>
 __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
                                                    int probe_bias, uint32_t *rows_buf, int64_t stride_words,
-                                                   unsigned long long *n_matches, unsigned long long *alg_bytes) {
+                                                   unsigned long long *n_matches, unsigned long long *alg_bytes,
+                                                   unsigned long long *alg_bytes3) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
     const int RB = dcap / BIG_ROWS_PER_WG;
@@ -890,7 +891,7 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
     __syncthreads();
 
     const int Wall = lay.W1 ? 32 + lay.W1 : lay.W0;  // words of a whole row in the stage
-    uint64_t bytes = 0, tri = 0;
+    uint64_t bytes = 0, bytes3 = 0, tri = 0;  // bytes3: level 3, the work of the count kernel on these rows
     const int i_end = min(d, i0 + BIG_ROWS_PER_WG);
     for (int i = i0 + wave; i < i_end; i += 4) {
         const int32_t v = U[i];
@@ -918,7 +919,7 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
                     if (jb >= Wall * 32) break;
                     const bool bit = live[k] && ((word[k] >> sh[k]) & 1u);
                     unsigned long long mask = __ballot(bit);
-                    if (K >= 4 && bit) bytes += per_arc + 4ull * Dp[jb + lane];
+                    if (K >= 4 && bit) bytes3 += per_arc + 4ull * Dp[jb + lane];
                     if (K == 3) tri += bit;
                     if (lane == 0) {
                         stage[jb >> 5] = (uint32_t)mask;
@@ -934,7 +935,7 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
                 int j = clq_hash_find(htab, hmask, hshift, U, adj[p]);
                 if (j >= 0) {
                     atomicOr(stage + (j >> 5), 1u << (j & 31));
-                    if (K >= 4) bytes += per_arc + 4ull * Dp[j];
+                    if (K >= 4) bytes3 += per_arc + 4ull * Dp[j];
                     if (K == 3) tri += 1;
                 }
             }
@@ -954,9 +955,11 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
     for (int i = i0 + tid; i < i_end; i += 256) bytes += 8ull + 4ull * ((uint64_t)d + Dp[i]);
     if (i0 == 0 && tid == 0) bytes += 4ull + 4ull * (uint64_t)d;
     bytes = wave_sum_u64(bytes);
+    bytes3 = wave_sum_u64(bytes3);
     tri = wave_sum_u64(tri);
     if (lane == 0) {
         if (bytes) atomicAdd(alg_bytes + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)bytes);
+        if (bytes3) atomicAdd(alg_bytes3 + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)bytes3);
         if (K == 3 && tri) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)tri);
     }
 }

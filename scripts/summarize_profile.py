@@ -18,7 +18,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
-SEARCH = ("k_clique", "k_tail", "k_extend", "k_ranges", "k_filter_roots", "k_batch_end", "k_sum_slots")
+SEARCH = ("k_clique", "k_clq_", "k_cycle4", "k_tail", "k_leaf_pair", "k_extend", "k_ranges", "k_filter_roots", "k_batch_end",
+          "k_sum_slots")
+# kernel family (the names gpm_hip_kernel_name returns) -> prefixes of the kernels in it
+FAMILIES = {"k_tail": ("k_tail", "k_leaf_pair"), "k_extend": ("k_extend",), "k_clique": ("k_clique<",),
+            "k_clq_build": ("k_clq_build",), "k_clq_count4": ("k_clq_count4",), "k_cycle4": ("k_cycle4_light", "k_cycle4_heavy")}
 
 
 def short(name):
@@ -80,18 +84,23 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
     json.dump(summary, f, indent=1)
     f.write("\n")
 
-# 3. HBM bytes per launch of the intersection kernel (all size classes together),
-#    the same "per launch" basis as bench.py's roofline.achieved
-tail = [v for k, v in summary.items() if k.startswith(("k_clique<", "k_tail"))]
-calls = sum(v["calls"] for v in tail)
-hbm = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in tail)
-ms = sum(v["total_ms"] for v in tail)
-with open(os.path.join(dst, "tail_traffic.json"), "w") as f:
-    json.dump({"source": f"profiles/{tag}_pmc_summary.json", "launches": calls, "hbm_bytes_total": hbm,
-               "hbm_bytes_per_launch": hbm / calls if calls else None, "kernel_ms_total": ms,
-               "kernel_avg_ms": ms / calls if calls else None,
-               "note": "read bytes = 2 x FETCH_SIZE KiB (gfx950 correction, calibrated with scripts/calib_fetch), "
-                       "write bytes = WRITE_SIZE KiB; one benchmark step"}, f, indent=1)
+# 3. HBM bytes per launch of every kernel family, the same "per launch" basis as
+#    bench.py's roofline.achieved; the counters cover every search of the profiled run
+traffic = {"note": "read bytes = 2 x FETCH_SIZE KiB (gfx950 correction, calibrated with scripts/calib_fetch), "
+                   "write bytes = WRITE_SIZE KiB; sums over the whole profiled run (warm-up and timed steps)",
+           "source": f"profiles/{tag}_pmc_summary.json"}
+for fam, prefixes in FAMILIES.items():
+    part = [v for k, v in summary.items() if k.startswith(prefixes)]
+    calls = sum(v["calls"] for v in part)
+    if not calls:
+        continue
+    hbm = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in part)
+    ms = sum(v["total_ms"] for v in part)
+    traffic[fam] = {"launches": calls, "hbm_bytes_total": hbm, "hbm_bytes_per_launch": hbm / calls,
+                    "kernel_ms_total": ms, "kernel_avg_ms": ms / calls,
+                    "hbm_GBps_while_running": hbm / 1e9 / (ms / 1e3) if ms else None}
+with open(os.path.join(dst, "hbm_traffic.json"), "w") as f:
+    json.dump(traffic, f, indent=1)
     f.write("\n")
 for name in ("trace.json",):
     p = os.path.join(src, name)
