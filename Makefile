@@ -9,8 +9,8 @@ ARCH    ?= gfx950
 CFLAGS  ?= -O2 -std=c99 -Wall -Wextra -fPIC
 HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-result
 LIBDIR  := mpi_amd/lib
-HOST_SRC := mpi_amd/host/utils.c mpi_amd/host/graph.c mpi_amd/host/plan.c
-HOST_HDR := mpi_amd/host/utils.h mpi_amd/host/graph.h mpi_amd/host/plan.h include/gpm_hip.h
+HOST_SRC := mpi_amd/host/utils.c mpi_amd/host/graph.c mpi_amd/host/loader.c mpi_amd/host/plan.c
+HOST_HDR := mpi_amd/host/utils.h mpi_amd/host/graph.h mpi_amd/host/loader.h mpi_amd/host/plan.h include/gpm_hip.h
 
 all: $(LIBDIR)/libgpm_hip.so $(LIBDIR)/libgpm_host.so gpm-par.exe
 
@@ -20,10 +20,10 @@ $(LIBDIR)/libgpm_hip.so: mpi_amd/csrc/gpm_hip.hip mpi_amd/csrc/gpm_kernels.hpp m
 
 $(LIBDIR)/libgpm_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
-	$(CC) $(CFLAGS) -shared -o $@ $(HOST_SRC)
+	$(CC) $(CFLAGS) -shared -o $@ $(HOST_SRC) -lpthread
 
 gpm-par.exe: mpi_amd/host/gpm-par.c $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libgpm_hip.so
-	$(CC) $(CFLAGS) -o $@ mpi_amd/host/gpm-par.c $(HOST_SRC) -L$(LIBDIR) -lgpm_hip -Wl,-rpath,'$$ORIGIN/$(LIBDIR)'
+	$(CC) $(CFLAGS) -o $@ mpi_amd/host/gpm-par.c $(HOST_SRC) -L$(LIBDIR) -lgpm_hip -lpthread -Wl,-rpath,'$$ORIGIN/$(LIBDIR)'
 
 oracle:
 	$(MAKE) -C oracle all

@@ -2,10 +2,15 @@
 #include "graph.h"
 
 #include <ctype.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include "loader.h"
 #include "utils.h"
 
 #define MAX_LINE 63 /* the reference reads lines into char[64] (src/graph.c:41) */
@@ -238,13 +243,27 @@ int readInputBuffer(const char *buf, int64_t len, Graph **data, Pattern **patter
     *pattern = NULL;
     Scan s = {buf, buf + len, 0};
     Section ds, ps;
-    if (scanSection(&s, &ds, err, errLen) != 0) {
-        sectionFree(&ds);
-        return -1;
+    Graph *g = NULL;
+    {
+        /* fast path: well-formed data sections are parsed by several threads */
+        Scan t = s;
+        int64_t n = 0, lines = 0;
+        const char *next = NULL;
+        if (scanCount(&t, &n) == 0 && n >= 0 && n <= INT32_MAX - 1 &&
+            (g = loadDataSectionParallel(t.p, t.end, n, loaderThreads(), &next, &lines)) != NULL) {
+            s.p = next;
+            s.lineNo = t.lineNo + lines;
+        }
     }
-    Graph *g = graphFromSection(&ds, err, errLen);
-    sectionFree(&ds);
-    if (!g) return -1;
+    if (!g) {
+        if (scanSection(&s, &ds, err, errLen) != 0) {
+            sectionFree(&ds);
+            return -1;
+        }
+        g = graphFromSection(&ds, err, errLen);
+        sectionFree(&ds);
+        if (!g) return -1;
+    }
     if (scanSection(&s, &ps, err, errLen) != 0) {
         sectionFree(&ps);
         freeGraph(g);
@@ -299,6 +318,21 @@ int readInputBuffer(const char *buf, int64_t len, Graph **data, Pattern **patter
 }
 
 int readInput(const char *path, Graph **data, Pattern **pattern, char *err, int errLen) {
+    /* map the file when possible: the loader's threads then page it in side by side */
+    int fd = open(path, O_RDONLY);
+    if (fd >= 0) {
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                close(fd);
+                int r = readInputBuffer(m, (int64_t)st.st_size, data, pattern, err, errLen);
+                munmap(m, (size_t)st.st_size);
+                return r;
+            }
+        }
+        close(fd);
+    }
     FILE *f = fopen(path, "rb");
     if (!f) return fail(err, errLen, "cannot open input", 0);
     fseek(f, 0, SEEK_END);
