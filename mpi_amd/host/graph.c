@@ -346,6 +346,48 @@ int readInput(const char *path, Graph **data, Pattern **pattern, char *err, int 
     return r;
 }
 
+/* Decimal text of v at p; returns the end. */
+static char *putInt(char *p, int64_t v) {
+    char tmp[24];
+    int k = 0;
+    do {
+        tmp[k++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (k) *p++ = tmp[--k];
+    return p;
+}
+
+int writeDataSection(const char *path, int32_t n, const int64_t *outOffsets, const int32_t *outEdges) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    const size_t cap = (size_t)1 << 22;
+    char *buf = safeMalloc(cap + 64), *p = buf;
+    p = putInt(p, n);
+    *p++ = '\n';
+    int ok = 1;
+    for (int32_t v = 0; v < n && ok; ++v) {
+        int64_t b = outOffsets[v], e = outOffsets[v + 1];
+        if (e == b) continue; /* a "<v> 0" block crashes the reference */
+        p = putInt(p, (int64_t)v + 1);
+        *p++ = ' ';
+        p = putInt(p, e - b);
+        *p++ = '\n';
+        for (int64_t i = b; i < e; ++i) {
+            p = putInt(p, (int64_t)outEdges[i] + 1);
+            *p++ = '\n';
+            if ((size_t)(p - buf) > cap) {
+                ok = fwrite(buf, 1, (size_t)(p - buf), f) == (size_t)(p - buf);
+                p = buf;
+            }
+        }
+    }
+    *p++ = '\n'; /* the blank line that ends the section */
+    ok = ok && fwrite(buf, 1, (size_t)(p - buf), f) == (size_t)(p - buf);
+    free(buf);
+    return (fclose(f) == 0 && ok) ? 0 : -1;
+}
+
 Graph *graphFromEdges(int32_t n, const int32_t *src, const int32_t *dst, int64_t m) {
     Graph *g = safeCalloc(1, sizeof *g);
     g->nodesCount = n;

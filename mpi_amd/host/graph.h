@@ -45,6 +45,12 @@ typedef struct {
 int readInput(const char *path, Graph **data, Pattern **pattern, char *err, int errLen);
 int readInputBuffer(const char *buf, int64_t len, Graph **data, Pattern **pattern, char *err, int errLen);
 
+/* Write the data-graph section of the input format (vertex count, one block
+ * per vertex with out-arcs, the blank line that ends the section) from a CSR
+ * with 0-based ids; the caller appends the pattern section.  Used by the
+ * benchmark generators.  Returns 0, or -1 on an I/O error. */
+int writeDataSection(const char *path, int32_t n, const int64_t *outOffsets, const int32_t *outEdges);
+
 /* Build a data graph from 0-based arcs (any order, duplicates allowed). */
 Graph *graphFromEdges(int32_t n, const int32_t *src, const int32_t *dst, int64_t m);
 /* Build a pattern from 0-based arcs in listing order. */

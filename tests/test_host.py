@@ -157,6 +157,18 @@ def test_threaded_loader_leaves_odd_input_to_the_parser(tmp_path, monkeypatch):
     assert _read_both_ways(str(tmp_path / "plain.in"), monkeypatch)[0][0] == "ok"
 
 
+def test_c_writer_writes_what_the_python_writer_writes(tmp_path):
+    spec = next(g for g in util.golden_specs() if g["name"] == "plaw9_tree5_labelled4")
+    text, dl, pl = util.build_input(spec)
+    n, s, d = util.build_graph(spec)
+    order = np.lexsort((d, s))
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(off, np.asarray(s, dtype=np.int64) + 1, 1)
+    p = tmp_path / "c.txt"
+    binding.write_input_csr(str(p), n, np.cumsum(off), np.asarray(d)[order], gen.PATTERNS[spec["pattern"]], dl, pl)
+    assert p.read_text() == text
+
+
 def test_symmetric_and_simple_flags(tmp_path):
     p = tmp_path / "a.in"
     p.write_text("3\n1 2\n2\n3\n2 1\n1\n3 1\n1\n\n2\n1 1\n2\n")
