@@ -135,6 +135,13 @@ typedef struct {
  * GPM_ESINK). */
 typedef int (*gpm_row_sink)(void *user, const int32_t *rows, uint64_t nrows, int32_t ncols);
 
+/* Text sink: called on the calling host thread with `bytes` bytes holding
+ * `nlines` whole output lines, "m(1) m(2) ... m(P)\n" with 1-based ids -- the
+ * bytes the reference's writeMatch prints (reference: src/gpm-par.c:71-77) --
+ * formatted on the GPU.  The buffer is only valid during the call.  Return 0
+ * to continue, non-zero to stop the search. */
+typedef int (*gpm_text_sink)(void *user, const char *text, size_t bytes, uint64_t nlines);
+
 const char *gpm_hip_last_error(void);
 
 /* Number of GPUs the runtime sees (0 when there is none). */
@@ -183,6 +190,12 @@ int gpm_hip_set_roots(gpm_ctx *ctx, int64_t lo, int64_t hi);
  * exactly once, in unspecified order.  *total receives this context's number
  * of embeddings. */
 int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, void *user, uint64_t *total);
+
+/* Output mode with the lines formatted on the GPU (replaces the per-match
+ * message and the fprintf per number on rank 0, reference: src/gpm-par.c:181,
+ * :608-613, :71-77): every match reaches `sink` exactly once as one text
+ * line, in blocks of whole lines, in unspecified order. */
+int gpm_hip_search_text(gpm_ctx *ctx, gpm_text_sink sink, void *user, uint64_t *total);
 
 int gpm_hip_stats(const gpm_ctx *ctx, gpm_stats *stats);
 

@@ -63,11 +63,13 @@ class gpm_stats(ctypes.Structure):
 PLAN_SYMMETRIC_DATA, PLAN_BREAK_SYMMETRY, PLAN_DEGREE_FILTER = 1, 2, 4
 ROW_SINK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_uint64,
                             ctypes.c_int32)
+TEXT_SINK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64)
 
 # every symbol include/gpm_hip.h declares
 HIP_SYMBOLS = ["gpm_hip_last_error", "gpm_hip_device_count", "gpm_hip_create", "gpm_hip_destroy",
                "gpm_hip_upload_graph", "gpm_hip_graph_info", "gpm_hip_set_plan", "gpm_hip_set_cursor",
-               "gpm_hip_set_roots", "gpm_hip_set_chunks", "gpm_hip_search", "gpm_hip_stats", "gpm_hip_kernel_name"]
+               "gpm_hip_set_roots", "gpm_hip_set_chunks", "gpm_hip_search", "gpm_hip_search_text", "gpm_hip_stats",
+               "gpm_hip_kernel_name"]
 
 _hip = None
 _host = None
@@ -92,6 +94,8 @@ def hip_lib():
         lib.gpm_hip_set_chunks.argtypes = [ctypes.c_void_p, ctypes.c_int64]
         lib.gpm_hip_search.argtypes = [ctypes.c_void_p, ctypes.c_int, ROW_SINK, ctypes.c_void_p,
                                        ctypes.POINTER(ctypes.c_uint64)]
+        lib.gpm_hip_search_text.argtypes = [ctypes.c_void_p, TEXT_SINK, ctypes.c_void_p,
+                                            ctypes.POINTER(ctypes.c_uint64)]
         lib.gpm_hip_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(gpm_stats)]
         lib.gpm_hip_kernel_name.restype = ctypes.c_char_p
         lib.gpm_hip_kernel_name.argtypes = [ctypes.c_int]
@@ -310,6 +314,23 @@ class Matcher:
         if len(out) != total.value:
             raise GpmError(f"sink saw {len(out)} rows, search reported {total.value}")
         return out
+
+    def findMatchesText(self) -> bytes:
+        """Run the search in output mode with the lines formatted on the GPU; returns the
+        output file's bytes (line order unspecified)."""
+        total = ctypes.c_uint64()
+        blocks, lines = [], [0]
+
+        def sink(_user, text, nbytes, nlines):
+            blocks.append(ctypes.string_at(text, nbytes))
+            lines[0] += nlines
+            return 0
+
+        cb = TEXT_SINK(sink)
+        self._check(self.lib.gpm_hip_search_text(self.ctx, cb, None, ctypes.byref(total)))
+        if lines[0] != total.value:
+            raise GpmError(f"sink saw {lines[0]} lines, search reported {total.value}")
+        return b"".join(blocks)
 
     def stats(self) -> gpm_stats:
         st = gpm_stats()

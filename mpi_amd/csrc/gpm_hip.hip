@@ -116,6 +116,13 @@ struct DevState {
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     int32_t *emit = nullptr, *emit_host = nullptr;
+    // text output: automorphism table, line offsets, text on the device and two pinned host buffers
+    int8_t *aut_dev = nullptr;
+    int64_t *line_off = nullptr;
+    char *text_dev = nullptr, *text_host[2] = {nullptr, nullptr};
+    int64_t text_lines_cap = 0, text_line_max = 0;
+    void *text_scan_tmp = nullptr;
+    size_t text_scan_bytes = 0;
     unsigned long long *ctr = nullptr;       // device counters
     unsigned long long *ctr_host = nullptr;  // pinned mirror for read-back
     int64_t *i64_dev = nullptr, *i64_host = nullptr;
@@ -145,6 +152,7 @@ struct DevState {
 
 struct RowBatch {
     std::vector<int32_t> rows;
+    std::vector<char> text;  // text mode: whole lines
     uint64_t nrows;
 };
 
@@ -322,6 +330,18 @@ static void free_buffers(DevState &d) {
     }
     dev_free(d.clq_slots);
     d.clq_slots = nullptr;
+    dev_free(d.aut_dev);
+    dev_free(d.line_off);
+    dev_free(d.text_dev);
+    dev_free(d.text_scan_tmp);
+    d.text_scan_tmp = nullptr;
+    host_free(d.text_host[0]);
+    host_free(d.text_host[1]);
+    d.aut_dev = nullptr;
+    d.line_off = nullptr;
+    d.text_dev = nullptr;
+    d.text_host[0] = d.text_host[1] = nullptr;
+    d.text_lines_cap = 0;
     dev_free(d.emit);
     host_free(d.emit_host);
     d.scan_tmp = nullptr;
@@ -852,6 +872,7 @@ struct SearchArgs {
     bool direct_sink;  // single GPU: rows go straight to the sink on this thread
     gpm_row_sink sink;
     void *user;
+    gpm_text_sink text_sink;  // non-null: matches leave as text lines formatted on the GPU
 };
 
 static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
@@ -896,6 +917,14 @@ static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
             HIP_TRY(hipMalloc(&sl.scratch,
                               (size_t)d.clq_scratch_blocks * (size_t)CLQ_MAX_D * (CLQ_MAX_D / 32) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&d.clq_slots, GPM_KERNEL_KINDS * CLQ_SLOTS * sizeof(unsigned long long)));
+    }
+    if (!count_only) {  // text output (allocated lazily by deliver_text) needs the automorphisms on the device
+        dev_free(d.aut_dev);
+        d.aut_dev = nullptr;
+        const size_t bytes = std::max<size_t>(1, ctx->aut.size());
+        HIP_TRY(hipMalloc(&d.aut_dev, bytes));
+        if (!ctx->aut.empty())
+            HIP_TRY(hipMemcpyAsync(d.aut_dev, ctx->aut.data(), ctx->aut.size(), hipMemcpyHostToDevice, d.stream));
     }
     if (want_emit > d.cap_emit) {
         dev_free(d.emit);
@@ -950,6 +979,90 @@ static int collect_times(DevState &d) {
     }
     d.events_used = 0;
     return GPM_OK;
+}
+
+// Text mode: the canonical rows emit[0, nrows) on the device become text lines
+// there (every automorphic image one line) and reach the sink in blocks of
+// whole lines.  Blocks are double-buffered: while the sink consumes one, the
+// next is formatted and copied.
+static int deliver_text(const SearchArgs &a, DevState &d, const int32_t *rows_dev, uint64_t nrows) {
+    gpm_ctx *ctx = a.ctx;
+    const int P = ctx->pv.P;
+    const int64_t n_aut = (int64_t)ctx->plan.n_aut;
+    hipStream_t s = d.stream;
+    if (nrows == 0) return GPM_OK;
+    const int64_t line_max = 11 * (int64_t)P;
+    if (!d.text_dev || d.text_line_max != line_max) {
+        dev_free(d.line_off);
+        dev_free(d.text_dev);
+        dev_free(d.text_scan_tmp);
+        host_free(d.text_host[0]);
+        host_free(d.text_host[1]);
+        d.line_off = nullptr, d.text_dev = nullptr, d.text_host[0] = d.text_host[1] = nullptr;
+        d.text_scan_tmp = nullptr;
+        d.text_lines_cap = std::max<int64_t>(n_aut, env_i64("GPM_TEXT_LINES", (int64_t)1 << 23));
+        d.text_line_max = line_max;
+        const size_t bytes = (size_t)d.text_lines_cap * (size_t)line_max;
+        HIP_TRY(hipMalloc(&d.line_off, ((size_t)d.text_lines_cap + 1) * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(&d.text_dev, bytes));
+        HIP_TRY(hipHostMalloc(&d.text_host[0], bytes));
+        HIP_TRY(hipHostMalloc(&d.text_host[1], bytes));
+        d.text_scan_bytes = 0;
+        HIP_TRY(rocprim::inclusive_scan(nullptr, d.text_scan_bytes, d.line_off + 1, d.line_off + 1,
+                                        (size_t)d.text_lines_cap, rocprim::plus<int64_t>(), s));
+        if (!d.text_scan_bytes) d.text_scan_bytes = 8;
+        HIP_TRY(hipMalloc(&d.text_scan_tmp, d.text_scan_bytes));
+    }
+    const int64_t rows_per_block = std::max<int64_t>(1, d.text_lines_cap / n_aut);
+    int cur = 0;
+    size_t pending_bytes = 0;   // block sitting in text_host[cur ^ 1], copy complete, not yet given to the sink
+    uint64_t pending_lines = 0;
+    auto flush = [&](int buf, size_t bytes, uint64_t lines) -> int {
+        if (!bytes) return GPM_OK;
+        if (a.direct_sink) {
+            if (a.text_sink(a.user, d.text_host[buf], bytes, lines) != 0) {
+                ctx->stop = true;
+                return fail(GPM_ESINK, "the sink stopped the search");
+            }
+            return GPM_OK;
+        }
+        RowBatch batch;
+        batch.nrows = lines;
+        batch.text.assign(d.text_host[buf], d.text_host[buf] + bytes);
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        ctx->cv.wait(lk, [&] { return ctx->queue.size() < 8 || ctx->stop; });
+        if (ctx->stop) return fail(GPM_ESINK, "the sink stopped the search");
+        ctx->queue.push_back(std::move(batch));
+        ctx->cv.notify_all();
+        return GPM_OK;
+    };
+    for (uint64_t r0 = 0; r0 < nrows && !ctx->stop; r0 += (uint64_t)rows_per_block) {
+        const int64_t nr = (int64_t)std::min<uint64_t>((uint64_t)rows_per_block, nrows - r0);
+        const int64_t nl = nr * n_aut;
+        const int32_t *rows = rows_dev + r0 * (uint64_t)P;
+        k_line_len<<<grid_for(nl), 256, 0, s>>>(rows, nr, P, (int)n_aut, d.aut_dev, d.line_off + 1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(d.line_off, 0, sizeof(int64_t), s));
+        size_t tmp_bytes = d.text_scan_bytes;
+        HIP_TRY(rocprim::inclusive_scan(d.text_scan_tmp, tmp_bytes, d.line_off + 1, d.line_off + 1, (size_t)nl,
+                                        rocprim::plus<int64_t>(), s));
+        HIP_TRY(hipMemcpyAsync(d.i64_host, d.line_off + nl, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const size_t bytes = (size_t)d.i64_host[0];
+        k_line_write<<<grid_for(nl), 256, 0, s>>>(rows, nr, P, (int)n_aut, d.aut_dev, d.line_off, d.text_dev);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(d.text_host[cur], d.text_dev, bytes, hipMemcpyDeviceToHost, s));
+        int rc = flush(cur ^ 1, pending_bytes, pending_lines);  // the sink works while the copy runs
+        if (rc) {
+            (void)hipStreamSynchronize(s);
+            return rc;
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        pending_bytes = bytes;
+        pending_lines = (uint64_t)nl;
+        cur ^= 1;
+    }
+    return flush(cur ^ 1, pending_bytes, pending_lines);
 }
 
 // Hand finished rows (pattern-vertex order, 1-based ids) to the sink, after
@@ -1070,7 +1183,11 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
                 uint64_t n_emit = 0;
                 rc = read_ctr(d, CTR_EMIT, &n_emit);
                 if (rc) return rc;
-                if (n_emit) {
+                if (n_emit && a.text_sink) {
+                    d.canonical += n_emit;
+                    rc = deliver_text(a, d, d.emit, n_emit);
+                    if (rc) return rc;
+                } else if (n_emit) {
                     HIP_TRY(hipMemcpyAsync(d.emit_host, d.emit, (size_t)n_emit * (size_t)P * sizeof(int32_t),
                                            hipMemcpyDeviceToHost, s));
                     HIP_TRY(hipStreamSynchronize(s));
@@ -1478,6 +1595,11 @@ static int device_search(const SearchArgs &a, DevState &d) {
                 for (uint64_t r0 = 0; r0 < n0; r0 += (uint64_t)d.cap_emit) {
                     uint64_t cnt = std::min<uint64_t>((uint64_t)d.cap_emit, n0 - r0);
                     k_emit_roots<<<grid_for((int64_t)cnt), 256, 0, s>>>((int64_t)cnt, d.F[0] + r0, d.perm, d.emit);
+                    if (a.text_sink) {
+                        rc = deliver_text(a, d, d.emit, cnt);
+                        if (rc) return rc;
+                        continue;
+                    }
                     HIP_TRY(hipMemcpyAsync(d.emit_host, d.emit, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost,
                                            s));
                     HIP_TRY(hipStreamSynchronize(s));
@@ -1524,10 +1646,11 @@ static int device_search(const SearchArgs &a, DevState &d) {
     return GPM_OK;
 }
 
-extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, void *user, uint64_t *total) {
+static int search_impl(gpm_ctx *ctx, int count_only, gpm_row_sink sink, gpm_text_sink text_sink, void *user,
+                       uint64_t *total) {
     if (!ctx) return fail(GPM_EINVAL, "null context");
     if (!ctx->have_graph || !ctx->have_plan) return fail(GPM_ESTATE, "upload a graph and set a plan first");
-    if (!count_only && !sink) return fail(GPM_EINVAL, "output mode needs a row sink");
+    if (!count_only && !sink && !text_sink) return fail(GPM_EINVAL, "output mode needs a sink");
     (void)hipGetLastError();
     const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     ctx->stop = false;
@@ -1536,7 +1659,7 @@ extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, v
         int prc = prepare_chunks(ctx);
         if (prc) return prc;
     }
-    SearchArgs a{ctx, count_only != 0, ctx->devs.size() == 1, sink, user};
+    SearchArgs a{ctx, count_only != 0, ctx->devs.size() == 1, sink, user, text_sink};
     int rc = GPM_OK;
     if (ctx->devs.size() == 1) {
         rc = device_search(a, ctx->devs[0]);
@@ -1569,7 +1692,9 @@ extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, v
                 ctx->queue.pop_front();
                 ctx->cv.notify_all();
             }
-            if (sink && !ctx->stop && sink(user, batch.rows.data(), batch.nrows, ctx->pv.P) != 0) {
+            const bool is_text = text_sink != nullptr;
+            if (!ctx->stop && (is_text ? text_sink(user, batch.text.data(), batch.text.size(), batch.nrows) != 0
+                                       : (sink && sink(user, batch.rows.data(), batch.nrows, ctx->pv.P) != 0))) {
                 ctx->stop = true;
                 rc = fail(GPM_ESINK, "the row sink stopped the search");
                 ctx->cv.notify_all();
@@ -1649,6 +1774,15 @@ extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, v
         1e3 * (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
     if (total) *total = st.matches;
     return rc;
+}
+
+extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, void *user, uint64_t *total) {
+    return search_impl(ctx, count_only, sink, nullptr, user, total);
+}
+
+extern "C" int gpm_hip_search_text(gpm_ctx *ctx, gpm_text_sink sink, void *user, uint64_t *total) {
+    if (!sink) return fail(GPM_EINVAL, "text output needs a sink");
+    return search_impl(ctx, 0, nullptr, sink, user, total);
 }
 
 extern "C" const char *gpm_hip_kernel_name(int kind) {

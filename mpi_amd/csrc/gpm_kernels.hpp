@@ -1249,3 +1249,48 @@ __global__ __launch_bounds__(256) void k_cycle4_heavy(GraphView g, const int64_t
     if (lane == 0 && acc) atomicAdd(n_cycles, (unsigned long long)acc);
     if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
 }
+
+// ---------------------------------------------------------------------------
+// Output: matches as text lines, formatted on the GPU
+// ---------------------------------------------------------------------------
+//
+// The reference prints one line per match, "m(1) m(2) ... m(P)\n" with single
+// spaces (reference: writeMatch, src/gpm-par.c:71-77), one fprintf per number
+// on rank 0.  Here a canonical match row (pattern-vertex order, the caller's
+// 1-based ids) becomes n_aut lines, one per automorphic image; line lengths
+// are computed first, an exclusive scan places the lines, and a second kernel
+// writes the characters.  One thread per line.
+
+__device__ __forceinline__ int dec_digits(uint32_t x) {
+    return x < 10u ? 1 : x < 100u ? 2 : x < 1000u ? 3 : x < 10000u ? 4 : x < 100000u ? 5 : x < 1000000u ? 6
+         : x < 10000000u ? 7 : x < 100000000u ? 8 : x < 1000000000u ? 9 : 10;
+}
+
+// aut[a * P + v] = which column of the canonical row image a prints at place v.
+__global__ void k_line_len(const int32_t *rows, int64_t nrows, int P, int n_aut, const int8_t *aut, int64_t *len) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * n_aut) return;
+    const int32_t *m = rows + (idx / n_aut) * P;
+    int bytes = P;  // P - 1 spaces and the newline
+    for (int v = 0; v < P; ++v) bytes += dec_digits((uint32_t)m[v]);  // every image prints the same P ids
+    len[idx] = bytes;
+}
+
+__global__ void k_line_write(const int32_t *rows, int64_t nrows, int P, int n_aut, const int8_t *aut,
+                             const int64_t *off, char *text) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * n_aut) return;
+    const int32_t *m = rows + (idx / n_aut) * P;
+    const int8_t *im = aut + (idx % n_aut) * P;
+    char *p = text + off[idx];
+    for (int v = 0; v < P; ++v) {
+        uint32_t x = (uint32_t)m[n_aut > 1 ? im[v] : v];
+        const int nd = dec_digits(x);
+        for (int k = nd - 1; k >= 0; --k) {
+            p[k] = (char)('0' + x % 10u);
+            x /= 10u;
+        }
+        p += nd;
+        *p++ = v + 1 < P ? ' ' : '\n';
+    }
+}

@@ -17,6 +17,7 @@
  *   GPM_SYMBREAK    0 = enumerate every automorphic image on the GPU instead
  *                   of expanding canonical matches (default 1)
  *   GPM_STATS       1 = print search statistics to stderr
+ *   GPM_HOST_FORMAT 1 = format the output lines on the host instead of the GPU
  */
 #define _POSIX_C_SOURCE 200809L
 #include <stdio.h>
@@ -101,6 +102,13 @@ static int writeMatches(void *user, const int32_t *rows, uint64_t nrows, int32_t
     return 0;
 }
 
+/* Lines formatted on the GPU arrive as blocks of text. */
+static int writeText(void *user, const char *text, size_t bytes, uint64_t nlines) {
+    Writer *w = user;
+    (void)nlines;
+    return fwrite(text, 1, bytes, w->out) == bytes ? 0 : 1;
+}
+
 int main(int argc, char *argv[]) {
     if (launcherRank() != 0) return 0;
 
@@ -140,7 +148,9 @@ int main(int argc, char *argv[]) {
     int countOnly = envInt("GPM_COUNT_ONLY", 0);
     Writer w = {outFile, safeMalloc(1u << 22), 0, 1u << 22};
     uint64_t total = 0;
-    int rc = gpm_hip_search(ctx, countOnly, countOnly ? NULL : writeMatches, &w, &total);
+    int rc;
+    if (!countOnly && !envInt("GPM_HOST_FORMAT", 0)) rc = gpm_hip_search_text(ctx, writeText, &w, &total);
+    else rc = gpm_hip_search(ctx, countOnly, countOnly ? NULL : writeMatches, &w, &total);
     if (rc != 0) die("search failed", gpm_hip_last_error());
     if (w.len && fwrite(w.buf, 1, w.len, outFile) != w.len) die("write failed", argv[2]);
     fclose(outFile);

@@ -93,12 +93,38 @@ CLI_GOLDEN = [g for g in GOLDEN if g["name"] in ("er10k_triangle", "rmat10_cliqu
                                                  "plaw9_tree5_labelled4", "rand40_dir_tree5_dir")]
 
 
+@pytest.mark.parametrize("host_format", ["0", "1"], ids=["gpu_text", "host_text"])
 @pytest.mark.parametrize("spec", CLI_GOLDEN, ids=[g["name"] for g in CLI_GOLDEN])
-def test_cli_golden_files(spec, tmp_path):
+def test_cli_golden_files(spec, host_format, tmp_path):
+    """The program's output file, with the lines formatted on the GPU (default) or on the host."""
     text, _, _ = util.build_input(spec)
-    _, got = run_cli(text, tmp_path)
+    _, got = run_cli(text, tmp_path, env={"GPM_HOST_FORMAT": host_format})
     assert got.count(b"\n") == spec["count"]
     assert util.sorted_lines_md5(got) == spec["sorted_md5"]
+
+
+TEXT_SPECS = [g for g in GOLDEN if g["count"] <= ROWS_MAX and g["name"] in (
+    "rand9_sym_clique4", "rand9_dir_tree5_dir", "rand40_dir_rev4", "rmat8_triangle", "rmat8_cycle4", "rmat8_house",
+    "rmat10_clique4", "skew8_k6_minus_e", "plaw9_tree5_labelled4", "er10k_triangle", "rand9_dir_cycle4")]
+
+
+@pytest.mark.parametrize("block_lines", [None, "1000"], ids=["big_blocks", "tiny_blocks"])
+@pytest.mark.parametrize("spec", TEXT_SPECS, ids=[g["name"] for g in TEXT_SPECS])
+def test_text_lines_formatted_on_the_gpu(spec, block_lines, monkeypatch):
+    """gpm_hip_search_text: the bytes of the reference's output file (as a sorted multiset of
+    lines), incl. many small blocks through the double buffer, and with symmetry breaking off."""
+    if block_lines:
+        monkeypatch.setenv("GPM_TEXT_LINES", block_lines)
+    n, s, d = util.build_graph(spec)
+    dl, pl = util.build_labels(spec, n)
+    m = binding.Matcher(1)
+    upload(m, n, s, d, labels=dl)
+    for symbreak in (True, False):
+        m.set_pattern(gen.PATTERNS[spec["pattern"]], labels=pl, symbreak=symbreak)
+        text = m.findMatchesText()
+        assert text.count(b"\n") == spec["count"]
+        assert util.sorted_lines_md5(text) == spec["sorted_md5"]
+    m.close()
 
 
 VARIANTS = [
