@@ -29,6 +29,13 @@ struct GraphView {
     // without walking the list.
     int32_t nlab;
     const uint32_t *labcnt;
+    // Label-grouped copy of the lists (symmetric labelled graphs only, else
+    // nullptr): v's neighbours ordered by (label, id); labseg[v * (nlab + 1) + l]
+    // is where label l starts inside v's list.  A level that asks for a label
+    // takes its candidates from that segment alone instead of filtering the
+    // whole list; membership tests keep using the id-ordered lists.
+    const int32_t *adjL;
+    const uint32_t *labseg;
 };
 
 __device__ __forceinline__ bool hub_arc(const GraphView &g, int32_t from, int32_t to) {
@@ -99,10 +106,32 @@ __device__ __forceinline__ bool in_list(const GraphView &g, int dir, int part, i
     return contains_g(g.adj[dir], b, e, c);
 }
 
-// Candidate range of one level for the partial match m: the source list cut
-// down by the ordering bounds (c > every lower bound, c < every upper bound).
+// Does this level draw its candidates from a label segment?
+__device__ __forceinline__ bool from_segment(const GraphView &g, const LevelPlan &lv) {
+    return lv.label >= 0 && g.adjL != nullptr;
+}
+
+// Candidate range of one level for the partial match m: positions [b, e) of
+// `arr`, the source list (or its segment of the level's label) cut down by the
+// ordering bounds (c > every lower bound, c < every upper bound).
 __device__ __forceinline__ void source_range(const GraphView &g, const LevelPlan &lv, const int32_t *m, int64_t &b,
-                                             int64_t &e) {
+                                             int64_t &e, const int32_t *&arr) {
+    if (from_segment(g, lv)) {
+        const int32_t v = m[lv.src_level];
+        arr = g.adjL;
+        b = e = 0;
+        if (lv.label >= g.nlab) return;  // nobody carries this label
+        const uint32_t *seg = g.labseg + (size_t)v * (size_t)(g.nlab + 1) + (size_t)lv.label;
+        b = g.off[0][v] + seg[0];
+        e = g.off[0][v] + seg[1];
+        int32_t lo = lv.src_part == PART_ABOVE ? v : -1, hi = lv.src_part == PART_BELOW ? v : INT32_MAX;
+        for (int j = 0; j < lv.n_lower; ++j) lo = max(lo, m[lv.lower_level[j]]);
+        for (int j = 0; j < lv.n_upper; ++j) hi = min(hi, m[lv.upper_level[j]]);
+        if (lo >= 0) b = lower_bound_g(arr, b, e, lo + 1);
+        if (hi != INT32_MAX) e = lower_bound_g(arr, b, e, hi);
+        return;
+    }
+    arr = g.adj[lv.src_dir];
     list_range(g, lv.src_dir, lv.src_part, m[lv.src_level], b, e);
     if (lv.n_lower && !lv.lower_is_src) {
         int32_t lo = m[lv.lower_level[0]];
@@ -148,6 +177,13 @@ __device__ __forceinline__ bool accept(const GraphView &g, const LevelPlan &lv, 
 __device__ __forceinline__ uint64_t level_bytes(const GraphView &g, const LevelPlan &lv, const int32_t *m, int k) {
     int64_t b, e;
     list_range(g, lv.src_dir, lv.src_part, m[lv.src_level], b, e);
+    if (from_segment(g, lv)) {  // only the label's segment of the source list is streamed
+        b = e = 0;
+        if (lv.label < g.nlab) {
+            const uint32_t *seg = g.labseg + (size_t)m[lv.src_level] * (size_t)(g.nlab + 1) + (size_t)lv.label;
+            e = (int64_t)seg[1] - (int64_t)seg[0];
+        }
+    }
     uint64_t bytes = 4ull * (uint64_t)k + 4ull * (uint64_t)(e - b);
     for (int j = 0; j < lv.n_cons; ++j) {
         list_range(g, lv.cons_dir[j], lv.cons_part[j], m[lv.cons_level[j]], b, e);

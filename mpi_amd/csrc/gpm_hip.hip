@@ -107,7 +107,8 @@ struct DevState {
     int32_t *perm = nullptr;
     uint8_t *label = nullptr;
     uint32_t *hub = nullptr;
-    uint32_t *labcnt = nullptr;
+    uint32_t *labcnt = nullptr, *labseg = nullptr;
+    int32_t *adjL = nullptr;
     GraphView gv{};
     // search buffers
     int64_t cap_rows = 0, cap_emit = 0;
@@ -293,6 +294,10 @@ static void free_graph(DevState &d) {
     dev_free(d.label);
     dev_free(d.hub);
     dev_free(d.labcnt);
+    dev_free(d.labseg);
+    dev_free(d.adjL);
+    d.labseg = nullptr;
+    d.adjL = nullptr;
     dev_free(d.cyc_cost);
     dev_free(d.cyc_wp);
     d.cyc_wp = nullptr;
@@ -622,6 +627,36 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
             HIP_TRY(hipStreamSynchronize(s));
             d.gv.labcnt = d.labcnt;
         }
+    }
+    // label-grouped copy of the lists: labelled levels read one segment instead of filtering the list
+    d.gv.adjL = nullptr;
+    d.gv.labseg = nullptr;
+    const int64_t m_arcs = d.m[0];
+    if (d.gv.labcnt && m_arcs > 0 && env_i64("GPM_NO_LABEL_SEGMENTS", 0) == 0 &&
+        (size_t)n * (size_t)(d.gv.nlab + 1) * sizeof(uint32_t) <= ((size_t)4 << 30)) {
+        uint64_t *keys = nullptr, *keys2 = nullptr;
+        int32_t *vals = nullptr;
+        void *tmp = nullptr;
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipMalloc(&d.labseg, (size_t)n * (size_t)(d.gv.nlab + 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&d.adjL, ((size_t)m_arcs + 1) * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&keys, (size_t)m_arcs * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&keys2, (size_t)m_arcs * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&vals, (size_t)m_arcs * sizeof(int32_t)));
+        k_label_segments<<<grid_for(n), 256, 0, s>>>(d.gv, d.labcnt, d.labseg);
+        k_segment_keys<<<grid_for(m_arcs), 256, 0, s>>>(d.gv, m_arcs, keys, vals);
+        HIP_TRY(hipGetLastError());
+        const unsigned end_bit = 8u + (unsigned)bits_for(n);
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, d.adjL, (size_t)m_arcs, 0u, end_bit, s));
+        HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, d.adjL, (size_t)m_arcs, 0u, end_bit, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipFree(tmp));
+        HIP_TRY(hipFree(keys));
+        HIP_TRY(hipFree(keys2));
+        HIP_TRY(hipFree(vals));
+        d.gv.adjL = d.adjL;
+        d.gv.labseg = d.labseg;
     }
     return GPM_OK;
 }

@@ -122,7 +122,8 @@ __global__ void k_ranges(GraphView g, PlanView pl, int k, const int32_t *rows, i
         const int32_t *m = rows + r * k;
         const LevelPlan &lv = pl.lv[k];
         int64_t b, e;
-        source_range(g, lv, m, b, e);
+        const int32_t *arr;
+        source_range(g, lv, m, b, e, arr);
         beg[r] = b;
         cnt[r] = e - b;
         bytes = level_bytes(g, lv, m, k);
@@ -171,7 +172,7 @@ __global__ void k_extend(GraphView g, PlanView pl, int k, const int32_t *rows, c
         }
         const LevelPlan &lv = pl.lv[k];
         m = rows + lo * k;
-        c = g.adj[lv.src_dir][beg[lo] + (gi - pref[lo])];
+        c = (from_segment(g, lv) ? g.adjL : g.adj[lv.src_dir])[beg[lo] + (gi - pref[lo])];
         ok = accept(g, lv, m, k, c);
     }
     unsigned long long mask = __ballot(ok);
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
         // are tested per element.
         int walk = -1;  // -1 = source list, j = constraint j
         int64_t b, e;
-        source_range(g, la, m, b, e);
+        const int32_t *sarr;
+        source_range(g, la, m, b, e, sarr);
         int32_t lo_id = -1, hi_id = INT32_MAX;
         if (ti.any_shortest) {
             for (int j = 0; j < la.n_cons; ++j) {
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
                 for (int j = 0; j < la.n_upper; ++j) hi_id = min(hi_id, m[la.upper_level[j]]);
             }
         }
-        const int32_t *wadj = g.adj[walk < 0 ? la.src_dir : la.cons_dir[walk]];
+        const int32_t *wadj = walk < 0 ? sarr : g.adj[la.cons_dir[walk]];
         if (ti.twin) {
             // levels A and B are twins: |S| survivors give |S|(|S|-1) ordered pairs, or
             // half of that when an ordering bound ties B to A; nothing is staged
@@ -375,8 +377,8 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
                     wave_lds_sync();
                     if (lane == 0) bytes += level_bytes(g, lb, m, L + 1);
                     int64_t b2, e2;
-                    source_range(g, lb, m, b2, e2);
-                    const int32_t *badj = g.adj[lb.src_dir];
+                    const int32_t *badj;
+                    source_range(g, lb, m, b2, e2, badj);
                     for (int64_t i2 = b2 + lane; i2 < e2; i2 += GPM_WAVE) cnt += accept(g, lb, m, L + 1, badj[i2]);
                 }
             }
@@ -417,6 +419,36 @@ __global__ void k_leaf_pair(GraphView g, PlanView pl, TailInfo ti, const int32_t
         if (cnt) atomicAdd(n_matches, (unsigned long long)cnt);
         if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
     }
+}
+
+// Sort key of arc p = (v -> w) for the label-grouped copy of the lists:
+// (v << 8) | label(w); a stable sort keeps ids ascending inside every label.
+__global__ void k_segment_keys(GraphView g, int64_t m, uint64_t *keys, int32_t *vals) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    int32_t lo = 0, hi = g.n;  // last v with off[v] <= p
+    while (hi - lo > 1) {
+        int32_t mid = lo + ((hi - lo) >> 1);
+        if (g.off[0][mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    const int32_t w = g.adj[0][p];
+    keys[p] = ((uint64_t)(uint32_t)lo << 8) | g.label[w];
+    vals[p] = w;
+}
+
+// labseg[v][l] = neighbours of v with a label below l (nlab + 1 entries per vertex).
+__global__ void k_label_segments(GraphView g, const uint32_t *labcnt, uint32_t *labseg) {
+    int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n) return;
+    const uint32_t *cnt = labcnt + (size_t)v * (size_t)g.nlab;
+    uint32_t *seg = labseg + (size_t)v * (size_t)(g.nlab + 1);
+    uint32_t run = 0;
+    for (int l = 0; l < g.nlab; ++l) {
+        seg[l] = run;
+        run += cnt[l];
+    }
+    seg[g.nlab] = run;
 }
 
 // Neighbours per label of every vertex (thread per vertex).

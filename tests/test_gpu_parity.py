@@ -138,6 +138,7 @@ VARIANTS = [
     {"symbreak": True, "env": {"GPM_CLIQUE_MAX_D": "6"}},
     {"symbreak": True, "env": {"GPM_NO_CLIQUE": "1", "GPM_NO_REUSE": "1"}},
     {"symbreak": True, "env": {"GPM_NO_TWIN": "1", "GPM_NO_CYCLE4": "1"}},
+    {"symbreak": True, "env": {"GPM_NO_LABEL_SEGMENTS": "1"}},
 ]
 VAR_SPECS = [g for g in GOLDEN if g["name"] in (
     "rand9_sym_clique4", "rand9_sym_cycle4", "rand9_dir_tree5_dir", "rand40_dir_rev4", "rand40_dir_k4_dag",
@@ -311,6 +312,39 @@ def test_leaf_levels_counted_in_closed_form(pname, symbreak, labelled, monkeypat
         got.append(m.findMatches(count_only=True))
         m.close()
     assert got == [want, want]
+
+
+LABELLED = [("triangle", [0, 0, 1]), ("triangle", [2, 2, 2]), ("clique4", [0, 0, 1, 1]), ("clique4", [1, 1, 1, 1]),
+            ("cycle4", [0, 1, 0, 1]), ("cycle4", [0, 0, 1, 2]), ("house", [0, 1, 1, 0, 2]), ("diamond", [0, 1, 1, 0]),
+            ("path4", [1, 0, 0, 1]), ("star4", [0, 1, 1, 2]), ("tree5", [0, 1, 2, 3, 1]), ("k6_minus_e", [0, 0, 0, 0, 1, 1]),
+            ("tri_dir", [0, 1, 1]), ("rev4", [0, 1, 0, 1])]
+
+
+@pytest.mark.parametrize("segments", ["on", "off"])
+@pytest.mark.parametrize("pname,plabels", LABELLED, ids=[f"{p}-{''.join(map(str, l))}" for p, l in LABELLED])
+def test_labelled_patterns_equal_the_oracle(pname, plabels, segments, monkeypatch):
+    """Labelled patterns, incl. ones whose automorphisms (and so the ordering bounds) survive the
+    labels: counts and match sets equal the oracle's, with the candidates taken from label
+    segments of the lists or filtered from whole lists, symmetry breaking on and off."""
+    if segments == "off":
+        monkeypatch.setenv("GPM_NO_LABEL_SEGMENTS", "1")
+    directed = pname in ("tri_dir", "rev4")
+    if directed:
+        s, d = util.rand_digraph(60, 1, 5, 4, False)
+        n = 60
+    else:
+        n, s, d = util.build_graph({"graph": "rmat", "scale": 9, "ef": 8, "seed": 2})
+    dl = gen.vertex_labels(n, 4 if pname == "tree5" else 3, seed=5).numpy().astype(np.int32)
+    want, want_rows, _ = util.oracle_matches(n, s, d, gen.PATTERNS[pname], data_labels=dl, pattern_labels=plabels)
+    m = binding.Matcher(1)
+    upload(m, n, s, d, labels=dl)
+    for symbreak in (True, False):
+        m.set_pattern(gen.PATTERNS[pname], labels=plabels, symbreak=symbreak)
+        assert m.findMatches(count_only=True) == want, (pname, plabels, symbreak)
+        if want <= 200_000:
+            rows = m.findMatches(count_only=False)
+            assert sorted(map(tuple, rows.tolist())) == sorted(map(tuple, want_rows.tolist()))
+    m.close()
 
 
 def test_counts_are_reduced_over_rccl(monkeypatch):
