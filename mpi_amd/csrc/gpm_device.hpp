@@ -57,6 +57,7 @@ struct LevelPlan {
 
 struct PlanView {
     int32_t P;
+    int8_t simple;           // data graph without duplicate arcs: any operand list may be the one walked
     int8_t order[GPM_MAXP];  // pattern vertex bound at each level
     LevelPlan lv[GPM_MAXP];
 };
@@ -143,6 +144,35 @@ __device__ __forceinline__ void source_range(const GraphView &g, const LevelPlan
         for (int j = 1; j < lv.n_upper; ++j) hi = min(hi, m[lv.upper_level[j]]);
         e = lower_bound_g(g.adj[lv.src_dir], b, e, hi);
     }
+}
+
+// The list a level walks for the partial match m: the source list, or on a
+// simple graph the shortest of the source and constraint lists (the result set
+// is the same), cut down exactly by the ordering bounds.  walk = -1 for the
+// source list, else the index of the constraint whose list is walked.
+__device__ __forceinline__ void walk_range(const GraphView &g, const PlanView &pl, const LevelPlan &lv,
+                                           const int32_t *m, int64_t &b, int64_t &e, const int32_t *&arr, int &walk) {
+    source_range(g, lv, m, b, e, arr);
+    walk = -1;
+    if (!pl.simple || lv.n_cons == 0) return;
+    int64_t best = e - b;
+    for (int j = 0; j < lv.n_cons; ++j) {
+        int64_t cb, ce;
+        list_range(g, lv.cons_dir[j], lv.cons_part[j], m[lv.cons_level[j]], cb, ce);
+        if (ce - cb < best) {
+            best = ce - cb;
+            b = cb;
+            e = ce;
+            walk = j;
+        }
+    }
+    if (walk < 0) return;
+    arr = g.adj[lv.cons_dir[walk]];
+    int32_t lo = -1, hi = INT32_MAX;
+    for (int j = 0; j < lv.n_lower; ++j) lo = max(lo, m[lv.lower_level[j]]);
+    for (int j = 0; j < lv.n_upper; ++j) hi = min(hi, m[lv.upper_level[j]]);
+    if (lo >= 0) b = lower_bound_g(arr, b, e, lo + 1);
+    if (hi != INT32_MAX) e = lower_bound_g(arr, b, e, hi);
 }
 
 // Per-vertex filters of a level: label and minimum degrees.

@@ -114,6 +114,7 @@ struct DevState {
     int64_t cap_rows = 0, cap_emit = 0;
     int32_t *F[GPM_MAXP] = {};
     int64_t *beg[GPM_MAXP] = {}, *cnt[GPM_MAXP] = {}, *pref[GPM_MAXP] = {};
+    int8_t *wsel[GPM_MAXP] = {};  // which operand list each row walks at the next level
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     int32_t *emit = nullptr, *emit_host = nullptr;
@@ -319,6 +320,8 @@ static void free_buffers(DevState &d) {
         dev_free(d.beg[k]);
         dev_free(d.cnt[k]);
         dev_free(d.pref[k]);
+        dev_free(d.wsel[k]);
+        d.wsel[k] = nullptr;
         d.F[k] = nullptr;
         d.beg[k] = d.cnt[k] = d.pref[k] = nullptr;
     }
@@ -770,6 +773,7 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
     PlanView &pv = ctx->pv;
     memset(&pv, 0, sizeof pv);
     pv.P = P;
+    pv.simple = ctx->info.simple && env_i64("GPM_NO_SHORTEST", 0) == 0;
     for (int k = 0; k < P; ++k) {
         pv.order[k] = (int8_t)p->order[k];
         LevelPlan &lv = pv.lv[k];
@@ -928,6 +932,7 @@ static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
         if (!d.F[k]) HIP_TRY(hipMalloc(&d.F[k], (size_t)d.cap_rows * (size_t)(k + 1) * sizeof(int32_t)));
         if (!d.beg[k]) HIP_TRY(hipMalloc(&d.beg[k], (size_t)d.cap_rows * sizeof(int64_t)));
         if (!d.cnt[k]) HIP_TRY(hipMalloc(&d.cnt[k], (size_t)d.cap_rows * sizeof(int64_t)));
+        if (!d.wsel[k]) HIP_TRY(hipMalloc(&d.wsel[k], (size_t)d.cap_rows));
         if (!d.pref[k]) {
             HIP_TRY(hipMalloc(&d.pref[k], ((size_t)d.cap_rows + 1) * sizeof(int64_t)));
             HIP_TRY(hipMemsetAsync(d.pref[k], 0, sizeof(int64_t), d.stream));
@@ -1160,6 +1165,24 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
         HIP_TRY(hipGetLastError());
         return timed_end(d);
     }
+    if (a.count_only && ctx->use_tail && k == P - 2 && ctx->ti.twin && env_i64("GPM_TWIN_GROUP", 1) > 0) {
+        const int64_t G = env_i64("GPM_TWIN_GROUP", 1);
+        const unsigned blocks = (unsigned)std::min<int64_t>((nrows * G + 255) / 256, 1 << 16);
+        int rc = timed_begin(d, GPM_KIND_TAIL, nrows);
+        if (rc) return rc;
+#define TWIN_LAUNCH(GG)                                                                                        \
+    k_tail_twin<GG><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, rows, nrows, d.ctr + CTR_TAIL_MATCHES, \
+                                           d.ctr + CTR_TAIL_BYTES)
+        if (G >= 64) TWIN_LAUNCH(64);
+        else if (G >= 16) TWIN_LAUNCH(16);
+        else if (G >= 8) TWIN_LAUNCH(8);
+        else if (G >= 4) TWIN_LAUNCH(4);
+        else if (G >= 2) TWIN_LAUNCH(2);
+        else TWIN_LAUNCH(1);
+#undef TWIN_LAUNCH
+        HIP_TRY(hipGetLastError());
+        return timed_end(d);
+    }
     if (a.count_only && ctx->use_tail && k == P - 2) {
         unsigned blocks = (unsigned)std::min<int64_t>((nrows + TAIL_WAVES - 1) / TAIL_WAVES, 16384);
         int rc = timed_begin(d, GPM_KIND_TAIL, nrows);
@@ -1172,7 +1195,7 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
     }
 
     // candidate ranges and their prefix sums
-    k_ranges<<<grid_for(nrows), 256, 0, s>>>(d.gv, ctx->pv, k, rows, nrows, d.beg[k - 1], d.cnt[k - 1],
+    k_ranges<<<grid_for(nrows), 256, 0, s>>>(d.gv, ctx->pv, k, rows, nrows, d.beg[k - 1], d.cnt[k - 1], d.wsel[k - 1],
                                              d.ctr + CTR_BYTES);
     HIP_TRY(hipGetLastError());
     size_t tmp_bytes = d.scan_tmp_bytes;
@@ -1202,7 +1225,7 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
             if (rc) return rc;
             if (terminal && a.count_only) {
                 k_extend<MODE_COUNT><<<grid_for(gcount), 256, 0, s>>>(d.gv, ctx->pv, k, rows, d.pref[k - 1],
-                                                                      d.beg[k - 1], b0, b1, g0, g1, nullptr,
+                                                                      d.beg[k - 1], d.wsel[k - 1], b0, b1, g0, g1, nullptr,
                                                                       d.ctr + CTR_MATCHES, nullptr);
                 HIP_TRY(hipGetLastError());
                 rc = timed_end(d);
@@ -1210,7 +1233,7 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
             } else if (terminal) {
                 HIP_TRY(hipMemsetAsync(d.ctr + CTR_EMIT, 0, sizeof(unsigned long long), s));
                 k_extend<MODE_EMIT><<<grid_for(gcount), 256, 0, s>>>(d.gv, ctx->pv, k, rows, d.pref[k - 1],
-                                                                     d.beg[k - 1], b0, b1, g0, g1, d.emit,
+                                                                     d.beg[k - 1], d.wsel[k - 1], b0, b1, g0, g1, d.emit,
                                                                      d.ctr + CTR_EMIT, d.perm);
                 HIP_TRY(hipGetLastError());
                 rc = timed_end(d);
@@ -1233,7 +1256,7 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
             } else {
                 HIP_TRY(hipMemsetAsync(d.ctr + CTR_LEVEL0 + k, 0, sizeof(unsigned long long), s));
                 k_extend<MODE_EXTEND><<<grid_for(gcount), 256, 0, s>>>(d.gv, ctx->pv, k, rows, d.pref[k - 1],
-                                                                       d.beg[k - 1], b0, b1, g0, g1, d.F[k],
+                                                                       d.beg[k - 1], d.wsel[k - 1], b0, b1, g0, g1, d.F[k],
                                                                        d.ctr + CTR_LEVEL0 + k, nullptr);
                 HIP_TRY(hipGetLastError());
                 rc = timed_end(d);

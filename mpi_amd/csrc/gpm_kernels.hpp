@@ -115,7 +115,7 @@ __global__ void k_filter_roots(GraphView g, LevelPlan lv0, int64_t lo, int64_t h
 // how many there are (after the ordering bounds).  Also sums the merge-model
 // bytes of this level.
 __global__ void k_ranges(GraphView g, PlanView pl, int k, const int32_t *rows, int64_t nrows, int64_t *beg,
-                         int64_t *cnt, unsigned long long *alg_bytes) {
+                         int64_t *cnt, int8_t *wsel, unsigned long long *alg_bytes) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t bytes = 0;
     if (r < nrows) {
@@ -123,9 +123,11 @@ __global__ void k_ranges(GraphView g, PlanView pl, int k, const int32_t *rows, i
         const LevelPlan &lv = pl.lv[k];
         int64_t b, e;
         const int32_t *arr;
-        source_range(g, lv, m, b, e, arr);
+        int walk;
+        walk_range(g, pl, lv, m, b, e, arr, walk);
         beg[r] = b;
         cnt[r] = e - b;
+        wsel[r] = (int8_t)walk;
         bytes = level_bytes(g, lv, m, k);
     }
     bytes = wave_sum_u64(bytes);
@@ -157,8 +159,8 @@ enum { MODE_EXTEND = 0, MODE_COUNT = 1, MODE_EMIT = 2 };
 //                with the caller's 1-based ids
 template <int MODE>
 __global__ void k_extend(GraphView g, PlanView pl, int k, const int32_t *rows, const int64_t *pref, const int64_t *beg,
-                         int64_t r0, int64_t r1, int64_t g0, int64_t g1, int32_t *out, unsigned long long *n_out,
-                         const int32_t *perm) {
+                         const int8_t *wsel, int64_t r0, int64_t r1, int64_t g0, int64_t g1, int32_t *out,
+                         unsigned long long *n_out, const int32_t *perm) {
     int64_t gi = g0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool ok = false;
     int32_t c = 0;
@@ -172,8 +174,10 @@ __global__ void k_extend(GraphView g, PlanView pl, int k, const int32_t *rows, c
         }
         const LevelPlan &lv = pl.lv[k];
         m = rows + lo * k;
-        c = (from_segment(g, lv) ? g.adjL : g.adj[lv.src_dir])[beg[lo] + (gi - pref[lo])];
-        ok = accept(g, lv, m, k, c);
+        const int walk = wsel[lo];  // which operand list this row walks (see walk_range)
+        const int32_t *arr = walk >= 0 ? g.adj[lv.cons_dir[walk]] : from_segment(g, lv) ? g.adjL : g.adj[lv.src_dir];
+        c = arr[beg[lo] + (gi - pref[lo])];
+        ok = accept(g, lv, m, k, c, walk);
     }
     unsigned long long mask = __ballot(ok);
     if (!mask) return;
@@ -384,6 +388,62 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
             }
             n_staged = 0;
             wave_lds_sync();
+        }
+    }
+    cnt = wave_sum_u64(cnt);
+    bytes = wave_sum_u64(bytes);
+    if (lane == 0) {
+        if (cnt) atomicAdd(n_matches, (unsigned long long)cnt);
+        if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
+    }
+}
+
+// Twin last levels (TailInfo::twin) with G lanes per partial match instead of a
+// whole wave: the lists walked here are mostly far shorter than 64 entries, so
+// 64/G partial matches share a wave.  Nothing is staged: |S| survivors of level
+// A give |S|(|S|-1) ordered pairs, or half of that under an ordering bound
+// between the twins.
+template <int G>
+__global__ __launch_bounds__(256) void k_tail_twin(GraphView g, PlanView pl, TailInfo ti, const int32_t *rows,
+                                                   int64_t nrows, unsigned long long *n_matches,
+                                                   unsigned long long *alg_bytes) {
+    const int lane = lane_id(), sub = lane & (G - 1);
+    const int L = pl.P - 2;
+    const LevelPlan &la = pl.lv[L];
+    const int64_t groups = (int64_t)gridDim.x * (blockDim.x / G);
+    uint64_t cnt = 0, bytes = 0;
+    for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G; r < nrows; r += groups) {
+        const int32_t *m = rows + r * L;
+        int walk = -1;
+        int64_t b, e;
+        const int32_t *sarr;
+        source_range(g, la, m, b, e, sarr);
+        int32_t lo_id = -1, hi_id = INT32_MAX;
+        for (int j = 0; j < la.n_cons; ++j) {  // twins only exist on simple graphs: any list may be walked
+            int64_t cb, ce;
+            list_range(g, la.cons_dir[j], la.cons_part[j], m[la.cons_level[j]], cb, ce);
+            if (ce - cb < e - b) {
+                b = cb;
+                e = ce;
+                walk = j;
+            }
+        }
+        if (walk >= 0) {
+            for (int j = 0; j < la.n_lower; ++j) lo_id = max(lo_id, m[la.lower_level[j]]);
+            for (int j = 0; j < la.n_upper; ++j) hi_id = min(hi_id, m[la.upper_level[j]]);
+        }
+        const int32_t *wadj = walk < 0 ? sarr : g.adj[la.cons_dir[walk]];
+        uint32_t s_cnt = 0;
+        for (int64_t i = b + sub; i < e; i += G) {
+            const int32_t c = wadj[i];
+            s_cnt += c > lo_id && c < hi_id && accept(g, la, m, L, c, walk);
+        }
+        for (int o = G / 2; o > 0; o >>= 1) s_cnt += __shfl_xor(s_cnt, o, GPM_WAVE);
+        if (sub == 0) {
+            const uint64_t s_all = s_cnt;
+            const uint64_t pairs = s_all * (s_all - (s_all ? 1 : 0));
+            cnt += (ti.b_lower_is_a || ti.b_upper_is_a) ? pairs / 2 : pairs;
+            bytes += (s_all + 1) * level_bytes(g, la, m, L) + 4ull * s_all;
         }
     }
     cnt = wave_sum_u64(cnt);
