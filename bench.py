@@ -36,21 +36,64 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(twin_scale, ef, pattern_name, budget_s=120):
+# The five benchmark configurations: data graph, pattern, and the scaled-down twin the CPU baseline runs on.
+CONFIGS = {
+    1: {"graph": {"graph": "er", "n": 10000, "m": 50000, "seed": 1}, "pattern": "triangle",
+        "twin": {"graph": "er", "n": 10000, "m": 50000, "seed": 1}},
+    2: {"graph": {"graph": "rmat", "scale": 20, "ef": 16, "seed": 1}, "pattern": "cycle4",
+        "twin": {"graph": "rmat", "scale": 9, "ef": 16, "seed": 1}},
+    3: {"graph": {"graph": "rmat", "scale": 24, "ef": 16, "seed": 1}, "pattern": "clique4",
+        "twin": {"graph": "rmat", "scale": 10, "ef": 16, "seed": 1}},
+    4: {"graph": {"graph": "plaw", "n": 1 << 22, "avg_deg": 16, "seed": 1}, "pattern": "tree5", "labels": 16,
+        "pattern_labels": [0, 1, 2, 3, 1], "twin": {"graph": "plaw", "n": 1 << 10, "avg_deg": 6, "seed": 1}},
+    5: {"graph": {"graph": "rmat", "scale": 18, "ef": 8, "abcd": (0.7, 0.1, 0.1, 0.1), "seed": 1},
+        "pattern": "k6_minus_pm",
+        "twin": {"graph": "rmat", "scale": 9, "ef": 8, "abcd": (0.7, 0.1, 0.1, 0.1), "seed": 1}},
+}
+
+
+def describe(spec):
+    if spec["graph"] == "er":
+        return f"Erdos-Renyi n={spec['n']} m={spec['m']} seed {spec['seed']}"
+    if spec["graph"] == "rmat":
+        a, b, c, d = spec.get("abcd", (0.57, 0.19, 0.19, 0.05))
+        return (f"R-MAT scale-{spec['scale']} ef-{spec['ef']} (a,b,c,d)=({a:g},{b:g},{c:g},{d:g}) seed {spec['seed']}"
+                .replace("0.", "."))
+    return f"power-law (exponent 2.1) n={spec['n']} avg-deg {spec['avg_deg']} seed {spec['seed']}"
+
+
+def generate(spec, device):
+    """CSR (offsets, adjacency) of a benchmark graph, built on `device`."""
+    if spec["graph"] == "er":
+        return spec["n"], *gen.erdos_renyi(spec["n"], spec["m"], seed=spec["seed"], device=device)
+    if spec["graph"] == "rmat":
+        return 1 << spec["scale"], *gen.rmat(spec["scale"], spec["ef"], abcd=tuple(spec.get("abcd", (0.57, 0.19, 0.19, 0.05))),
+                                             seed=spec["seed"], device=device)
+    return spec["n"], *gen.power_law(spec["n"], avg_deg=spec["avg_deg"], seed=spec["seed"], device=device)
+
+
+def cpu_baseline(cfg, budget_s=120):
     """The reference (built from its own sources into oracle/_ref) timed under
     `mpirun -np 2` -- one worker, its fastest configuration -- on a scaled-down
     twin of the workload; falls back to the oracle (a port) when the reference
-    binary or mpirun is not available."""
+    binary or mpirun is not available, and for labelled patterns, which the
+    reference cannot read."""
     from tests import util
-    n, s, d = util.build_graph({"graph": "rmat", "scale": twin_scale, "ef": ef, "seed": 1})
+    pattern_name = cfg["pattern"]
+    n, off, adj = generate(cfg["twin"], "cpu")
+    s, d = gen.edges_from_csr(*gen.csr_to_numpy(off, adj))
     pat = gen.PATTERNS[pattern_name]
-    sample = f"R-MAT scale-{twin_scale} ef-{ef} twin of the workload, {pattern_name}, full output to a file"
+    dl = pl = None
+    if "labels" in cfg:
+        dl = gen.vertex_labels(n, cfg["labels"], seed=cfg["twin"]["seed"]).numpy().astype(np.int32)
+        pl = cfg["pattern_labels"]
+    sample = f"{describe(cfg['twin'])} twin of the workload, {pattern_name}, full output to a file"
     with tempfile.TemporaryDirectory() as tmp:
         inp, out = os.path.join(tmp, "in.txt"), os.path.join(tmp, "out.txt")
-        gen.write_input(inp, n, s, d, pat)
+        gen.write_input(inp, n, s, d, pat, dl, pl)
         ref = os.path.join(ROOT, "oracle", "_ref", "gpm-par-ref")
         mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
-        if os.path.exists(ref) and os.path.exists(mpirun):
+        if dl is None and os.path.exists(ref) and os.path.exists(mpirun):
             try:
                 t0 = time.time()
                 subprocess.run([mpirun, "-np", "2", ref, inp, out], check=True, stdout=subprocess.DEVNULL,
@@ -67,6 +110,8 @@ def cpu_baseline(twin_scale, ef, pattern_name, budget_s=120):
         t0 = time.time()
         count = lib.oracle_run_file(inp.encode(), out.encode(), 0)
         dt = time.time() - t0
+        if dl is not None:
+            sample += " (the reference has no labels: every unlabelled match is enumerated, then filtered)"
         return {"value": count / dt, "unit": "matches/s", "cores": 1, "kind": "port", "sample": sample,
                 "matches": int(count), "seconds": round(dt, 3)}
 
@@ -76,12 +121,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scale", type=int, default=24)
-    ap.add_argument("--ef", type=int, default=16)
-    ap.add_argument("--pattern", default="clique4")
-    ap.add_argument("--twin-scale", type=int, default=10)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
+                    help="benchmark configuration; 3 (R-MAT scale-24 4-clique) is the headline")
+    ap.add_argument("--scale", type=int, default=None, help="override the R-MAT scale of the configuration")
+    ap.add_argument("--pattern", default=None, help="override the pattern of the configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    cfg["graph"] = dict(cfg["graph"])
+    if args.scale is not None and cfg["graph"]["graph"] == "rmat":
+        cfg["graph"]["scale"] = args.scale
+    if args.pattern is not None:
+        cfg["pattern"] = args.pattern
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -101,18 +152,21 @@ def main():
             dist.init_process_group(backend)
 
     t0 = time.time()
-    off, adj = gen.rmat(args.scale, args.ef, seed=1, device=dev)
-    n = 1 << args.scale
+    n, off, adj = generate(cfg["graph"], dev)
     m_arcs = int(off[-1].item())
+    labels = plabels = None
+    if "labels" in cfg and args.pattern is None:
+        labels = gen.vertex_labels(n, cfg["labels"], seed=cfg["graph"]["seed"], device=dev).cpu().numpy()
+        plabels = cfg["pattern_labels"]
     off_h, adj_h = off.cpu().numpy(), adj.cpu().numpy()
     del off, adj
     torch.cuda.empty_cache()
     t_gen = time.time() - t0
     t0 = time.time()
     matcher = binding.Matcher(1, devices=[dev_index])
-    info = matcher.upload(n, off_h, adj_h)
+    info = matcher.upload(n, off_h, adj_h, labels=labels)
     del off_h, adj_h
-    plan = matcher.set_pattern(gen.PATTERNS[args.pattern])
+    plan = matcher.set_pattern(gen.PATTERNS[cfg["pattern"]], labels=plabels)
     t_upload = time.time() - t0
     if rank == 0:
         log(f"graph: n={n} arcs={m_arcs} max_deg={info.max_out_deg} generate {t_gen:.1f}s upload+renumber "
@@ -182,8 +236,9 @@ def main():
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": f"R-MAT scale-{args.scale} ef-{args.ef} (a,b,c,d)=(.57,.19,.19,.05) seed 1, "
-                                   f"symmetrised, {args.pattern}, count-only",
+            "config": {"workload": f"{describe(cfg['graph'])}, symmetrised, {cfg['pattern']}"
+                                   f"{' with ' + str(cfg['labels']) + ' vertex labels' if labels is not None else ''}"
+                                   f", count-only", "benchmark_config": args.config,
                        "vertices": n, "arcs": m_arcs, "parallelism": f"roots sharded over {world} GPU(s), "
                        "graph replicated, shared chunk cursor"},
             "matches": total,
@@ -195,7 +250,7 @@ def main():
             "search_ms_rank0": st.ms_total,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.twin_scale, args.ef, args.pattern)
+            line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
 
     matcher.close()

@@ -115,7 +115,8 @@ typedef struct {
     uint64_t matches;                      /* embeddings (all automorphic images) */
     uint64_t canonical;                    /* matches before multiplying by n_aut */
     uint64_t rows_in[GPM_MAX_PATTERN];     /* partial matches of length k+1 that were extended */
-    uint64_t alg_bytes;                    /* merge-model bytes of the work done */
+    uint64_t alg_bytes;                    /* merge-model bytes of the work done: per extended partial
+                                            * match, its ids plus one pass over every operand list */
     uint64_t tail_alg_bytes;               /* part of alg_bytes done by the fused intersection kernel */
     double   ms_total;                     /* wall time of the last search */
     double   ms_tail_kernel;               /* summed device time of the intersection kernel */

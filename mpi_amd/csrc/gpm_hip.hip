@@ -70,6 +70,7 @@ struct EventPair {
     hipEvent_t a, b;
     int kind;  // GPM_KIND_*
     int64_t rows;
+    int tag;   // size class of a clique launch (for GPM_TRACE), else 0
 };
 
 static const char *const kKindNames[GPM_KERNEL_KINDS] = {"k_tail", "k_extend", "k_clique", "k_clq_build",
@@ -986,7 +987,7 @@ static int read_ctr(DevState &d, int slot, uint64_t *out) {
     return GPM_OK;
 }
 
-static int timed_begin(DevState &d, int kind, int64_t rows = 0, hipStream_t stream = nullptr) {
+static int timed_begin(DevState &d, int kind, int64_t rows = 0, hipStream_t stream = nullptr, int tag = 0) {
     if (d.events_used == d.events.size()) {
         EventPair ev{};
         ev.kind = kind;
@@ -996,6 +997,7 @@ static int timed_begin(DevState &d, int kind, int64_t rows = 0, hipStream_t stre
     }
     d.events[d.events_used].kind = kind;
     d.events[d.events_used].rows = rows;
+    d.events[d.events_used].tag = tag;
     HIP_TRY(hipEventRecord(d.events[d.events_used].a, stream ? stream : d.stream));
     return GPM_OK;
 }
@@ -1012,8 +1014,8 @@ static int collect_times(DevState &d) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d.events[i].a, d.events[i].b));
         if (getenv("GPM_TRACE"))
-            fprintf(stderr, "gpm trace: %s rows %lld ms %.3f\n", kKindNames[d.events[i].kind],
-                    (long long)d.events[i].rows, ms);
+            fprintf(stderr, "gpm trace: %s class %d rows %lld ms %.3f\n", kKindNames[d.events[i].kind],
+                    d.events[i].tag, (long long)d.events[i].rows, ms);
         d.ms_kind[d.events[i].kind] += ms;
         d.launches_kind[d.events[i].kind]++;
     }
@@ -1309,7 +1311,7 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[6], in
         const int phases = dcap > 1024 ? 3 : 1;
         for (int64_t b0 = 0; b0 < (int64_t)n[c]; b0 += batch) {
             const int64_t nb = std::min<int64_t>(batch, (int64_t)n[c] - b0);
-            if ((rc = timed_begin(d, GPM_KIND_CLQ_BUILD, nb, s))) return rc;
+            if ((rc = timed_begin(d, GPM_KIND_CLQ_BUILD, nb, s, c))) return rc;
             k_clq_build<K><<<(unsigned)(nb * (dcap / BIG_ROWS_PER_WG)), 256, lds_build, s>>>(
                 d.gv, list + b0, nb, dcap, bias, sl.rows, stride, cnt, byt, byt3);
             HIP_TRY(hipGetLastError());
@@ -1317,7 +1319,7 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[6], in
             if (K == 4) {
                 HIP_TRY(hipFuncSetAttribute((const void *)k_clq_count4<SEG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds_count));
-                if ((rc = timed_begin(d, GPM_KIND_CLQ_COUNT, nb, s))) return rc;
+                if ((rc = timed_begin(d, GPM_KIND_CLQ_COUNT, nb, s, c))) return rc;
                 k_clq_count4<SEG><<<(unsigned)(nb * phases * SEG), 512, lds_count, s>>>(d.gv, list + b0, nb, dcap,
                                                                                         sl.rows, stride, cnt);
                 HIP_TRY(hipGetLastError());
@@ -1341,7 +1343,7 @@ static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[6]) {
     } else {
         if (n[4]) {  // rows in global scratch, persistent workgroups
             unsigned blocks = (unsigned)std::min<uint64_t>(n[4], (uint64_t)d.clq_scratch_blocks);
-            if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[4], s))) return rc;
+            if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[4], s, 4))) return rc;
             k_clique<K, 256, false><<<blocks, 256, clq_lds_bytes(K, 256, CLQ_MAX_D, false), s>>>(
                 d.gv, l + 4 * st, (int64_t)n[4], CLQ_MAX_D, bias, sl.scratch, cnt, byt);
             HIP_TRY(hipGetLastError());
@@ -1352,7 +1354,7 @@ static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[6]) {
             const size_t lds = clq_lds_bytes(K, 512, 1024, true);
             HIP_TRY(hipFuncSetAttribute((const void *)k_clique<K, 512, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[c], s))) return rc;
+            if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[c], s, c))) return rc;
             k_clique<K, 512, true><<<(unsigned)n[c], 512, lds, s>>>(d.gv, l + c * st, (int64_t)n[c], 1024, bias,
                                                                     nullptr, cnt, byt);
             HIP_TRY(hipGetLastError());
@@ -1360,14 +1362,14 @@ static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[6]) {
         }
     }
     if (n[1]) {
-        if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[1], s))) return rc;
+        if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[1], s, 1))) return rc;
         k_clique<K, 256, true><<<(unsigned)n[1], 256, clq_lds_bytes(K, 256, 256, true), s>>>(
             d.gv, l + st, (int64_t)n[1], 256, bias, nullptr, cnt, byt);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d, s))) return rc;
     }
     if (n[0]) {
-        if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[0], s))) return rc;
+        if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[0], s, 0))) return rc;
         k_clique<K, 64, true><<<(unsigned)n[0], 64, clq_lds_bytes(K, 64, 64, true), s>>>(d.gv, l, (int64_t)n[0], 64, bias,
                                                                                      nullptr, cnt, byt);
         HIP_TRY(hipGetLastError());

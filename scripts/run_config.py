@@ -1,4 +1,4 @@
-"""Run one of the five BASELINE.json configurations at full size on one GPU (count-only)
+"""Run one of the five benchmark configurations at full size on one GPU (count-only)
 and print the count, the wall time and the device statistics."""
 import json, sys, time
 import torch
