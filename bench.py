@@ -193,19 +193,26 @@ def main():
     t0 = time.perf_counter()
     kinds = binding.KINDS
     k_ms, k_bytes, k_launches = [0.0] * kinds, [0] * kinds, [0] * kinds
+    search_ms = 0.0
     for _ in range(args.steps):
         total = step()
         st = matcher.stats()  # HIP-event times of every launch, on the streams the kernels ran on
+        search_ms += st.ms_total
         for k in range(kinds):
             k_ms[k] += st.kernel_ms[k]
             k_bytes[k] += st.kernel_alg_bytes[k]
             k_launches[k] += st.kernel_launches[k]
     fence()
     elapsed = time.perf_counter() - t0
+    busy = [search_ms]  # per-rank time inside the search: the spread shows how well the chunks balance
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([search_ms], dtype=torch.float64, device=coll_dev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        busy = [float(p.item()) for p in parts]
     st = matcher.stats()
     sec_per_step = elapsed / max(args.steps, 1)
 
@@ -247,7 +254,7 @@ def main():
                          "alg_bytes_per_launch": k_bytes[dom] / max(k_launches[dom], 1),
                          "avg_launch_ms": k_ms[dom] / max(k_launches[dom], 1), "launches": k_launches[dom]},
             "kernel_families_rank0": families,
-            "search_ms_rank0": st.ms_total,
+            "search_ms_per_step_by_rank": [round(b / max(args.steps, 1), 3) for b in busy],
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
