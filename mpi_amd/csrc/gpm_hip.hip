@@ -419,7 +419,8 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->use_clique = env_i64("GPM_NO_CLIQUE", 0) == 0;
     ctx->use_cycle4 = env_i64("GPM_NO_CYCLE4", 0) == 0;
     ctx->cyc_heavy_thr = std::max<int64_t>(1, env_i64("GPM_CYCLE4_HEAVY", (int64_t)1 << 21));
-    if (ngpus > 1 || env_i64("GPM_FORCE_RCCL", 0)) {
+    // GPM_NO_RCCL=1: per-GPU counts are summed on the host only (also lets two workers share one GPU in tests)
+    if ((ngpus > 1 && env_i64("GPM_NO_RCCL", 0) == 0) || env_i64("GPM_FORCE_RCCL", 0)) {
         if (!rccl().ok()) {
             gpm_hip_destroy(ctx);
             return fail(GPM_ENODEV, "a multi-GPU context needs librccl.so, which could not be loaded");

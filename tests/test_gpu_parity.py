@@ -362,6 +362,30 @@ def test_counts_are_reduced_over_rccl(monkeypatch):
     m.close()
 
 
+@pytest.mark.parametrize("workers", [2, 3])
+def test_several_workers_in_one_context(workers, monkeypatch):
+    """The multi-GPU driver of one context -- one host thread per worker, chunks from one cursor,
+    rows and text handed to the caller's thread -- with every worker on GPU 0."""
+    monkeypatch.setenv("GPM_NO_RCCL", "1")
+    for name in ("rmat10_clique4", "rmat8_house", "rmat10_cycle4", "plaw9_tree5_labelled4"):
+        spec = next(g for g in GOLDEN if g["name"] == name)
+        n, s, d = util.build_graph(spec)
+        dl, pl = util.build_labels(spec, n)
+        m = binding.Matcher(workers, devices=[0] * workers)
+        upload(m, n, s, d, labels=dl)
+        m.set_pattern(gen.PATTERNS[spec["pattern"]], labels=pl)
+        m.set_chunks(40)
+        assert m.findMatches(count_only=True) == spec["count"]
+        st = m.stats()
+        assert sum(st.chunks[:workers]) > 1
+        if spec["count"] <= ROWS_MAX:
+            rows = m.findMatches(count_only=False)
+            assert util.sorted_lines_md5(util.rows_to_text(rows)) == spec["sorted_md5"]
+            text = m.findMatchesText()
+            assert util.sorted_lines_md5(text) == spec["sorted_md5"]
+        m.close()
+
+
 def test_chunk_count_does_not_change_the_result():
     n, s, d = util.build_graph({"graph": "rmat", "scale": 12, "ef": 8, "seed": 1})
     m = binding.Matcher(1)
