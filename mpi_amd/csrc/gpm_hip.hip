@@ -1298,7 +1298,6 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[6], in
     unsigned long long *byt3 = d.clq_slots + (size_t)GPM_KIND_CLQ_COUNT * CLQ_SLOTS;  // level 3, done by the count kernel
     const int dcaps[3] = {512, 1024, 2048};
     const int64_t strides[3] = {512 * 16, 1024 * 32, 1024 * 32 + 2048 * 32};
-    constexpr int SEG = 4;
     int rc;
     for (int c = 4; c >= 2; --c) {  // longest-running class first
         if (!n[c]) continue;
@@ -1307,7 +1306,11 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[6], in
         const int64_t batch = (int64_t)(CLQ_ROWS_WORDS / (size_t)stride);
         const int32_t *list = sl.lists + (int64_t)c * d.clq_stride;
         const size_t lds_build = ((size_t)4 * dcap + 4 * 64) * sizeof(uint32_t);
-        const size_t lds_count = ((size_t)8 * 512 + (size_t)std::min(dcap, 1024) * (std::min(dcap, 1024) / 32)) *
+        // 16 waves hide the LDS latency of the big tiles better than 8; the J lists of 16 waves and a
+        // 128 KiB tile fill the 160 KiB of LDS exactly
+        const bool wide = dcap > 512 && env_i64("GPM_COUNT4_WAVES", 16) >= 16;
+        const int nw = wide ? 16 : 8, seg = wide ? 2 : 4;
+        const size_t lds_count = ((size_t)nw * 512 + (size_t)std::min(dcap, 1024) * (std::min(dcap, 1024) / 32)) *
                                  sizeof(uint32_t);
         const int phases = dcap > 1024 ? 3 : 1;
         for (int64_t b0 = 0; b0 < (int64_t)n[c]; b0 += batch) {
@@ -1318,11 +1321,18 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[6], in
             HIP_TRY(hipGetLastError());
             if ((rc = timed_end(d, s))) return rc;
             if (K == 4) {
-                HIP_TRY(hipFuncSetAttribute((const void *)k_clq_count4<SEG>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds_count));
                 if ((rc = timed_begin(d, GPM_KIND_CLQ_COUNT, nb, s, c))) return rc;
-                k_clq_count4<SEG><<<(unsigned)(nb * phases * SEG), 512, lds_count, s>>>(d.gv, list + b0, nb, dcap,
-                                                                                        sl.rows, stride, cnt);
+                if (wide) {
+                    HIP_TRY(hipFuncSetAttribute((const void *)k_clq_count4<2, 16>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
+                    k_clq_count4<2, 16><<<(unsigned)(nb * phases * seg), 1024, lds_count, s>>>(d.gv, list + b0, nb, dcap,
+                                                                                                sl.rows, stride, cnt);
+                } else {
+                    HIP_TRY(hipFuncSetAttribute((const void *)k_clq_count4<4, 8>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
+                    k_clq_count4<4, 8><<<(unsigned)(nb * phases * seg), 512, lds_count, s>>>(d.gv, list + b0, nb, dcap,
+                                                                                              sl.rows, stride, cnt);
+                }
                 HIP_TRY(hipGetLastError());
                 if ((rc = timed_end(d, s))) return rc;
             }

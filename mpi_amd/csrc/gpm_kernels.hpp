@@ -1056,14 +1056,13 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
     }
 }
 
-// grid = nroots * phases * SEG workgroups of 512 threads (phases = 1 for
-// dcap <= 1024, else 3).  LDS (words): J[8][512] (16-bit entries) | tile rows.
-template <int SEG>
-__global__ __launch_bounds__(512) void k_clq_count4(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
+// grid = nroots * phases * SEG workgroups of NW waves (phases = 1 for
+// dcap <= 1024, else 3).  LDS (words): J[NW][512] (16-bit entries) | tile rows.
+template <int SEG, int NW>
+__global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
                                                     const uint32_t *rows_buf, int64_t stride_words,
                                                     unsigned long long *n_matches) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    constexpr int NW = 8;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
     const int phases = dcap > 1024 ? 3 : 1;
     const int64_t ri = blockIdx.x / (phases * SEG);
@@ -1107,7 +1106,7 @@ __global__ __launch_bounds__(512) void k_clq_count4(GraphView g, const int32_t *
         const int nvec = (j_hi - j_lo) * Wt / 4;
         const uint4 *src = reinterpret_cast<const uint4 *>(tile_rows);
         uint4 *dst = reinterpret_cast<uint4 *>(tile);
-        for (int k = tid; k < nvec; k += 512) dst[k] = src[k];
+        for (int k = tid; k < nvec; k += NW * GPM_WAVE) dst[k] = src[k];
     }
     __syncthreads();
 
