@@ -846,11 +846,21 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
                 if (!IN_LDS) __threadfence_block();
                 wave_lds_sync();
                 const int64_t vb = mid[v], ve = off[v + 1];
-                for (int64_t p = vb + lane; p < ve; p += GPM_WAVE) {
-                    int j = clq_hash_find(htab, hmask, hshift, U, adj[p]);
-                    if (j >= 0) {
-                        atomicOr(row + (j >> 5), 1u << (j & 31));
-                        arcs_bytes += per_arc + 4ull * Dp[j];
+                for (int64_t p0 = vb; p0 < ve; p0 += 4 * GPM_WAVE) {  // four list reads in flight per lane
+                    int32_t w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int64_t p = p0 + k * GPM_WAVE + lane;
+                        w[k] = p < ve ? adj[p] : -1;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (w[k] < 0) continue;
+                        int j = clq_hash_find(htab, hmask, hshift, U, w[k]);
+                        if (j >= 0) {
+                            atomicOr(row + (j >> 5), 1u << (j & 31));
+                            arcs_bytes += per_arc + 4ull * Dp[j];
+                        }
                     }
                 }
             }
@@ -1023,12 +1033,22 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
             stage[lane] = 0;
             wave_lds_sync();
             const int64_t vb = mid[v], ve = off[v + 1];
-            for (int64_t p = vb + lane; p < ve; p += GPM_WAVE) {
-                int j = clq_hash_find(htab, hmask, hshift, U, adj[p]);
-                if (j >= 0) {
-                    atomicOr(stage + (j >> 5), 1u << (j & 31));
-                    if (K >= 4) bytes3 += per_arc + 4ull * Dp[j];
-                    if (K == 3) tri += 1;
+            for (int64_t p0 = vb; p0 < ve; p0 += 4 * GPM_WAVE) {  // four list reads in flight per lane
+                int32_t w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t p = p0 + k * GPM_WAVE + lane;
+                    w[k] = p < ve ? adj[p] : -1;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (w[k] < 0) continue;
+                    int j = clq_hash_find(htab, hmask, hshift, U, w[k]);
+                    if (j >= 0) {
+                        atomicOr(stage + (j >> 5), 1u << (j & 31));
+                        if (K >= 4) bytes3 += per_arc + 4ull * Dp[j];
+                        if (K == 3) tri += 1;
+                    }
                 }
             }
         }
