@@ -79,7 +79,7 @@ def hip_lib():
     """Load libgpm_hip.so (built by `make`); raises when it is missing."""
     global _hip
     if _hip is None:
-        path = os.path.join(LIB_DIR, "libgpm_hip.so")
+        path = os.environ.get("GPM_HIP_LIB") or os.path.join(LIB_DIR, "libgpm_hip.so")  # override: kernel experiments
         if not os.path.exists(path):
             raise GpmError(f"{path} is missing: run `make` (or __graft_entry__.build()) first")
         lib = ctypes.CDLL(path)

@@ -555,6 +555,9 @@ __global__ void k_hub_fill(GraphView g, uint32_t *bits) {
 // where L = lanes per row.
 
 #define CLQ_MAX_D 2048                 // largest universe (bits per row)
+#ifndef CLQ_GATHERS
+#define CLQ_GATHERS 4                  // independent hub-matrix gathers in flight per lane
+#endif
 #define CLQ_SLOTS 1024                 // result counters are spread over this many slots
 #define CLQ_CLASSES 6
 
@@ -812,12 +815,12 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
             if (v >= g.hub_base && (int64_t)Dp[i] * 16 >= (int64_t)probe_bias * (int64_t)(d - 1 - i)) {
                 const uint32_t *hrow = g.hub + (size_t)(v - g.hub_base) * (size_t)g.hub_wpr;
                 // 256 positions per trip: four independent gathers in flight (Wp*32 is a multiple of 128)
-                for (int j0 = 0; j0 < Wp * 32; j0 += 4 * GPM_WAVE) {
-                    uint32_t word[4];
-                    uint32_t sh[4];
-                    bool live[4];
+                for (int j0 = 0; j0 < Wp * 32; j0 += CLQ_GATHERS * GPM_WAVE) {
+                    uint32_t word[CLQ_GATHERS];
+                    uint32_t sh[CLQ_GATHERS];
+                    bool live[CLQ_GATHERS];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < CLQ_GATHERS; ++k) {
                         const int j = j0 + k * GPM_WAVE + lane;
                         live[k] = j > i && j < d;
                         word[k] = 0;
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
                         }
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < CLQ_GATHERS; ++k) {
                         const int jb = j0 + k * GPM_WAVE;
                         if (jb >= Wp * 32) break;
                         const bool bit = live[k] && ((word[k] >> sh[k]) & 1u);
@@ -1000,11 +1003,11 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
         const uint64_t per_arc = 12ull + 4ull * ((uint64_t)d + Dp[i]);
         if (v >= g.hub_base && (int64_t)Dp[i] * 16 >= (int64_t)probe_bias * (int64_t)(d - 1 - i)) {
             const uint32_t *hrow = g.hub + (size_t)(v - g.hub_base) * (size_t)g.hub_wpr;
-            for (int j0 = 0; j0 < Wall * 32; j0 += 4 * GPM_WAVE) {
-                uint32_t word[4], sh[4];
-                bool live[4];
+            for (int j0 = 0; j0 < Wall * 32; j0 += CLQ_GATHERS * GPM_WAVE) {
+                uint32_t word[CLQ_GATHERS], sh[CLQ_GATHERS];
+                bool live[CLQ_GATHERS];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < CLQ_GATHERS; ++k) {
                     const int j = j0 + k * GPM_WAVE + lane;
                     live[k] = j > i && j < d;
                     word[k] = 0;
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < CLQ_GATHERS; ++k) {
                     const int jb = j0 + k * GPM_WAVE;
                     if (jb >= Wall * 32) break;
                     const bool bit = live[k] && ((word[k] >> sh[k]) & 1u);
