@@ -1515,7 +1515,9 @@ static int prepare_chunks(gpm_ctx *ctx) {
                 ctx->cyc_heavy_paths.push_back(paths);
             }
         }
-    const int64_t want = ctx->chunk_hint > 0 ? ctx->chunk_hint : 32 * (int64_t)ctx->devs.size();
+    int64_t want = ctx->chunk_hint > 0 ? ctx->chunk_hint : 32 * (int64_t)ctx->devs.size();
+    // the two-path counts are exact costs and every chunk is one persistent launch: few, large chunks
+    if (cyc) want = std::max<int64_t>(1, want / 8);
     const int64_t target = std::max<int64_t>(1, hpref.back() / want);
     int64_t begin = 0;
     while (begin < nroots) {

@@ -1315,15 +1315,26 @@ __global__ __launch_bounds__(256) void k_cycle4_light(GraphView g, const int64_t
     const int wave = threadIdx.x / GPM_WAVE, lane = lane_id();
     uint32_t *cnt = dense + (size_t)(blockIdx.x + CYC_HEAVY_SLABS) * (size_t)stride;
     uint64_t acc = 0, bytes = 0;
+    // roots are claimed in batches: one atomic per root on a single word would serialise a chunk of a
+    // million light roots
+    const int64_t batch = max((int64_t)1, min((int64_t)256, (hi - lo) / ((int64_t)gridDim.x * 8)));
+    int64_t i = 0, i_end = 0;
     for (;;) {
-        __threadfence();  // the zeros of the last root are in place before the next root counts
-        __syncthreads();
-        if (threadIdx.x == 0) s_next = (long long)(lo + (int64_t)atomicAdd(queue, 1ull));
-        __syncthreads();
-        const int64_t i = s_next;
-        if (i >= hi) break;
+        if (i == i_end) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_next = (long long)(lo + (int64_t)atomicAdd(queue, (unsigned long long)batch));
+            __syncthreads();
+            i = s_next;
+            if (i >= hi) break;
+            i_end = min(hi, i + batch);
+        }
         const int64_t paths = cost[i] - 1;
-        if (paths >= heavy_thr || paths < 2) continue;  // a cycle needs two two-paths
+        if (paths >= heavy_thr || paths < 2) {  // a cycle needs two two-paths
+            ++i;
+            continue;
+        }
+        __threadfence();  // the zeros of the last root are in place before this root counts
+        __syncthreads();
         const int32_t v1 = (int32_t)(g.n - 1 - i);
         acc += cyc_wave_pass<false>(g, wp, v1, wave, 4, cnt, s_pre[wave], s_beg[wave]);
         // bytes of this root: its list and one prefix per arc, every two-path read and counted
@@ -1336,6 +1347,7 @@ __global__ __launch_bounds__(256) void k_cycle4_light(GraphView g, const int64_t
         } else {
             cyc_wave_pass<true>(g, wp, v1, wave, 4, cnt, s_pre[wave], s_beg[wave]);
         }
+        ++i;
     }
     acc = wave_sum_u64(acc);
     bytes = wave_sum_u64(bytes);
