@@ -1328,8 +1328,36 @@ __global__ __launch_bounds__(256) void k_cycle4_light(GraphView g, const int64_t
             if (i >= hi) break;
             i_end = min(hi, i + batch);
         }
+        if (i == s_next && batch > 1) {
+            // first the tiny roots of the batch (at most 64 two-paths), one wave each and no counter
+            // array: every lane takes one two-path and counts the lower lanes that end in the same vertex
+            for (int64_t t = i + wave; t < i_end; t += 4) {
+                const int64_t np = cost[t] - 1;
+                if (np < 2 || np > GPM_WAVE) continue;
+                const int32_t r1 = (int32_t)(g.n - 1 - t);
+                const int64_t lb = g.off[0][r1], le = g.mid[0][r1];
+                const int64_t base = wp[lb];
+                int32_t v3 = -1;
+                if (lane < np) {
+                    int64_t a = lb, ae = le;  // last arc with wp[a] - base <= lane
+                    while (ae - a > 1) {
+                        int64_t mid = a + ((ae - a) >> 1);
+                        if (wp[mid] - base <= lane) a = mid;
+                        else ae = mid;
+                    }
+                    v3 = g.adj[0][g.off[0][g.adj[0][a]] + (lane - (wp[a] - base))];
+                }
+                uint32_t same = 0;
+                for (int l = 0; l < (int)np - 1; ++l) {
+                    const int32_t x = __builtin_amdgcn_readlane(v3, l);
+                    same += l < lane && x == v3;
+                }
+                acc += same;
+                if (lane == 0) bytes += 8ull * (uint64_t)np + 4ull + 12ull * (uint64_t)(le - lb);
+            }
+        }
         const int64_t paths = cost[i] - 1;
-        if (paths >= heavy_thr || paths < 2) {  // a cycle needs two two-paths
+        if (paths >= heavy_thr || paths < 2 || (batch > 1 && paths <= GPM_WAVE)) {  // a cycle needs two two-paths
             ++i;
             continue;
         }

@@ -241,6 +241,32 @@ def test_cliques_in_complete_graphs_closed_form(n, pname):
     m.close()
 
 
+def test_two_path_counting_of_four_cycles_equals_the_generic_path(monkeypatch):
+    """R-MAT scale 16 with one, few and many chunks: heavy roots (whole grid), light roots (one
+    workgroup, counter array) and tiny roots (one wave, registers; only taken when a chunk holds
+    tens of thousands of roots) against the level-by-level path."""
+    off, adj = gen.rmat(16, 16, seed=1)
+    o, a = gen.csr_to_numpy(off, adj)
+    n = 1 << 16
+    monkeypatch.setenv("GPM_NO_CYCLE4", "1")
+    m = binding.Matcher(1)
+    m.upload(n, o, a)
+    m.set_pattern(gen.PATTERNS["cycle4"])
+    want = m.findMatches(count_only=True)
+    m.close()
+    monkeypatch.delenv("GPM_NO_CYCLE4")
+    monkeypatch.setenv("GPM_CYCLE4_HEAVY", "100000")
+    m = binding.Matcher(1)
+    m.upload(n, o, a)
+    m.set_pattern(gen.PATTERNS["cycle4"])
+    for chunks in (1, 8, 64, 4000):
+        m.set_chunks(chunks)
+        assert m.findMatches(count_only=True) == want, chunks
+    st = m.stats()
+    assert st.kernel_launches[5] > 0  # GPM_KIND_CYCLE4
+    m.close()
+
+
 def test_clique_kernel_equals_generic_path(monkeypatch):
     """Bitmap kernel vs level-by-level path on R-MAT scale 13, K = 3..6, incl. a mixed split of the roots."""
     n, s, d = util.build_graph({"graph": "rmat", "scale": 13, "ef": 8, "seed": 3})
