@@ -79,7 +79,7 @@ static const char *const kKindNames[GPM_KERNEL_KINDS] = {"k_tail", "k_extend", "
 // One chunk of the root range; in clique mode also its roots per size class.
 struct Chunk {
     int64_t lo, hi;
-    uint32_t n[6];
+    uint32_t n[CLQ_CLASSES];
 };
 
 // The clique path keeps several chunks in flight, each on its own stream with
@@ -1291,30 +1291,33 @@ static size_t clq_lds_bytes(int K, int block, int dcap, bool rows_in_lds) {
 // Classes 2..4 of a chunk through the build/count kernel pair (K = 3: the
 // build kernel counts the triangles itself; K = 4: tiled count).
 template <int K>
-static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[6], int bias) {
+static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CLASSES], int bias) {
     static_assert(K == 3 || K == 4, "build/count pair exists for triangles and 4-cliques");
     hipStream_t s = sl.stream;
     unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + (size_t)GPM_KIND_CLQ_BUILD * CLQ_SLOTS;
     unsigned long long *byt3 = d.clq_slots + (size_t)GPM_KIND_CLQ_COUNT * CLQ_SLOTS;  // level 3, done by the count kernel
-    const int dcaps[3] = {512, 1024, 2048};
-    const int64_t strides[3] = {512 * 16, 1024 * 32, 1024 * 32 + 2048 * 32};
+    const int dcaps[4] = {512, 1024, 2048, 4096};
+    const int64_t strides[4] = {512 * 16, 1024 * 32, (1024 + 2048) * 32, (1024 + 2048 + 3072 + 4096) * 32};
     int rc;
-    for (int c = 4; c >= 2; --c) {  // longest-running class first
+    for (int c = 5; c >= 2; --c) {  // longest-running class first
         if (!n[c]) continue;
         const int dcap = dcaps[c - 2];
         const int64_t stride = strides[c - 2];
         const int64_t batch = (int64_t)(CLQ_ROWS_WORDS / (size_t)stride);
         const int32_t *list = sl.lists + (int64_t)c * d.clq_stride;
-        const size_t lds_build = ((size_t)4 * dcap + 4 * 64) * sizeof(uint32_t);
+        const size_t lds_build = ((size_t)4 * dcap + 4 * 128) * sizeof(uint32_t);
         // 16 waves hide the LDS latency of the big tiles better than 8; the J lists of 16 waves and a
         // 128 KiB tile fill the 160 KiB of LDS exactly
         const bool wide = dcap > 512 && env_i64("GPM_COUNT4_WAVES", 16) >= 16;
         const int nw = wide ? 16 : 8, seg = wide ? 2 : 4;
         const size_t lds_count = ((size_t)nw * 512 + (size_t)std::min(dcap, 1024) * (std::min(dcap, 1024) / 32)) *
                                  sizeof(uint32_t);
-        const int phases = dcap > 1024 ? 3 : 1;
+        const int tcap = dcap > 1024 ? dcap / 1024 : 1, phases = tcap * (tcap + 1) / 2;
         for (int64_t b0 = 0; b0 < (int64_t)n[c]; b0 += batch) {
             const int64_t nb = std::min<int64_t>(batch, (int64_t)n[c] - b0);
+            if (lds_build > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void *)k_clq_build<K>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds_build));
             if ((rc = timed_begin(d, GPM_KIND_CLQ_BUILD, nb, s, c))) return rc;
             k_clq_build<K><<<(unsigned)(nb * (dcap / BIG_ROWS_PER_WG)), 256, lds_build, s>>>(
                 d.gv, list + b0, nb, dcap, bias, sl.rows, stride, cnt, byt, byt3);
@@ -1342,7 +1345,7 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[6], in
 }
 
 template <int K>
-static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[6]) {
+static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CLASSES]) {
     hipStream_t s = sl.stream;
     unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + (size_t)GPM_KIND_CLIQUE * CLQ_SLOTS;
     const int32_t *l = sl.lists;
@@ -1391,8 +1394,10 @@ static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[6]) {
 
 static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows);
 
-static int clique_max_d() {
-    return (int)std::min<int64_t>(CLQ_MAX_D, std::max<int64_t>(0, env_i64("GPM_CLIQUE_MAX_D", CLQ_MAX_D)));
+// Largest universe the bitmap kernels take for a K-clique (larger roots go through the generic path).
+static int clique_max_d(int K) {
+    const int64_t cap = K <= 4 ? CLQ_BIG_MAX_D : CLQ_MAX_D;
+    return (int)std::min<int64_t>(cap, std::max<int64_t>(0, env_i64("GPM_CLIQUE_MAX_D", cap)));
 }
 
 // One chunk of roots through the bitmap kernel, enqueued on the slot's stream
@@ -1403,10 +1408,10 @@ static int clique_chunk(const SearchArgs &a, DevState &d, ChunkSlot &sl, const C
     gpm_ctx *ctx = a.ctx;
     hipStream_t s = sl.stream;
     HIP_TRY(hipMemsetAsync(sl.counts, 0, 8 * sizeof(unsigned long long), s));
-    k_clique_bin<<<grid_for(ch.hi - ch.lo), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(), ch.lo, ch.hi, sl.lists,
+    k_clique_bin<<<grid_for(ch.hi - ch.lo), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx->clique_k), ch.lo, ch.hi, sl.lists,
                                                          d.clq_stride, sl.counts);
     HIP_TRY(hipGetLastError());
-    d.rows_in[0] += (uint64_t)ch.n[0] + ch.n[1] + ch.n[2] + ch.n[3] + ch.n[4];
+    d.rows_in[0] += (uint64_t)ch.n[0] + ch.n[1] + ch.n[2] + ch.n[3] + ch.n[4] + ch.n[5];
     int rc = GPM_OK;
     switch (ctx->clique_k) {
         case 3: rc = clique_launch<3>(d, sl, ch.n); break;
@@ -1420,11 +1425,12 @@ static int clique_chunk(const SearchArgs &a, DevState &d, ChunkSlot &sl, const C
         default: return fail(GPM_ERUNTIME, "clique size %d not supported", ctx->clique_k);
     }
     if (rc) return rc;
-    if (ch.n[5]) {
+    const int generic = CLQ_CLASSES - 1;  // roots too large for the bitmap kernels
+    if (ch.n[generic]) {
         HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipMemcpyAsync(d.F[0], sl.lists + 5 * d.clq_stride, (size_t)ch.n[5] * sizeof(int32_t),
-                               hipMemcpyDeviceToDevice, d.stream));
-        rc = expand(a, d, 1, (int64_t)ch.n[5]);
+        HIP_TRY(hipMemcpyAsync(d.F[0], sl.lists + (int64_t)generic * d.clq_stride,
+                               (size_t)ch.n[generic] * sizeof(int32_t), hipMemcpyDeviceToDevice, d.stream));
+        rc = expand(a, d, 1, (int64_t)ch.n[generic]);
     }
     return rc;
 }
@@ -1538,18 +1544,19 @@ static int prepare_chunks(gpm_ctx *ctx) {
         int64_t *dbounds = nullptr;
         unsigned int *table = nullptr;
         HIP_TRY(hipMalloc(&dbounds, (size_t)nch * sizeof(int64_t)));
-        HIP_TRY(hipMalloc(&table, (size_t)nch * 6 * sizeof(unsigned int)));
+        HIP_TRY(hipMalloc(&table, (size_t)nch * CLQ_CLASSES * sizeof(unsigned int)));
         HIP_TRY(hipMemcpyAsync(dbounds, bounds.data(), (size_t)nch * sizeof(int64_t), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemsetAsync(table, 0, (size_t)nch * 6 * sizeof(unsigned int), s));
-        k_chunk_classes<<<grid_for(nroots), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(), lo, hi, dbounds, nch,
+        HIP_TRY(hipMemsetAsync(table, 0, (size_t)nch * CLQ_CLASSES * sizeof(unsigned int), s));
+        k_chunk_classes<<<grid_for(nroots), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx->clique_k), lo, hi, dbounds, nch,
                                                          table);
-        std::vector<unsigned int> htable((size_t)nch * 6);
+        std::vector<unsigned int> htable((size_t)nch * CLQ_CLASSES);
         HIP_TRY(hipMemcpyAsync(htable.data(), table, htable.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipFree(dbounds));
         HIP_TRY(hipFree(table));
         for (int i = 0; i < nch; ++i)
-            for (int c = 0; c < 6; ++c) ctx->chunks[(size_t)i].n[c] = htable[(size_t)i * 6 + (size_t)c];
+            for (int c = 0; c < CLQ_CLASSES; ++c)
+                ctx->chunks[(size_t)i].n[c] = htable[(size_t)i * CLQ_CLASSES + (size_t)c];
     }
     ctx->chunks_valid = true;
     return GPM_OK;

@@ -554,17 +554,22 @@ __global__ void k_hub_fill(GraphView g, uint32_t *bits) {
 // population count -- |C ^ row_j| for 64/L values of j per wave instruction,
 // where L = lanes per row.
 
-#define CLQ_MAX_D 2048                 // largest universe (bits per row)
+#define CLQ_MAX_D 2048                 // largest universe (bits per row) of k_clique
+#define CLQ_BIG_MAX_D 4096             // ... of the build/count kernel pair (four column tiles)
 #ifndef CLQ_GATHERS
 #define CLQ_GATHERS 4                  // independent hub-matrix gathers in flight per lane
 #endif
 #define CLQ_SLOTS 1024                 // result counters are spread over this many slots
-#define CLQ_CLASSES 6
+#define CLQ_CLASSES 7
+
+__device__ __forceinline__ int clq_class(int64_t d, int max_d) {
+    return d > max_d ? CLQ_CLASSES - 1 : d <= 64 ? 0 : d <= 256 ? 1 : d <= 512 ? 2 : d <= 1024 ? 3 : d <= 2048 ? 4 : 5;
+}
 
 // Sort roots of a chunk into size classes by d = |N+(root)|; each class is a
 // compacted list (ballot + prefix popcount, one atomic per wave and class).
 //   class 0: K-1 <= d <= 64   1: d <= 256   2: d <= 512   3: d <= 1024
-//   4: d <= max_d <= CLQ_MAX_D   5: larger (generic path)
+//   4: d <= 2048   5: d <= 4096 (classes 4, 5 only up to max_d)   6: larger (generic path)
 __global__ void k_clique_bin(GraphView g, int K, int max_d, int64_t lo, int64_t hi, int32_t *lists,
                              int64_t list_stride, unsigned long long *counts) {
     int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -573,7 +578,7 @@ __global__ void k_clique_bin(GraphView g, int K, int max_d, int64_t lo, int64_t 
     if (i < hi) {
         v = (int32_t)(g.n - 1 - i);
         int64_t d = g.off[0][v + 1] - g.mid[0][v];
-        if (d >= K - 1) cls = d > max_d ? 5 : d <= 64 ? 0 : d <= 256 ? 1 : d <= 512 ? 2 : d <= 1024 ? 3 : 4;
+        if (d >= K - 1) cls = clq_class(d, max_d);
     }
     int lane = lane_id();
     for (int c = 0; c < CLQ_CLASSES; ++c) {
@@ -606,14 +611,14 @@ __global__ void k_chunk_classes(GraphView g, int K, int max_d, int64_t lo, int64
     int32_t v = (int32_t)(g.n - 1 - i);
     int64_t d = g.off[0][v + 1] - g.mid[0][v];
     if (d < K - 1) return;
-    int cls = d > max_d ? 5 : d <= 64 ? 0 : d <= 256 ? 1 : d <= 512 ? 2 : d <= 1024 ? 3 : 4;
+    int cls = clq_class(d, max_d);
     int a = 0, b = nchunks;  // last chunk whose first root is <= i
     while (b - a > 1) {
         int m = (a + b) >> 1;
         if (bounds[m] <= i) a = m;
         else b = m;
     }
-    atomicAdd(table + a * 6 + cls, 1u);
+    atomicAdd(table + a * CLQ_CLASSES + cls, 1u);
 }
 
 struct u32x4 {
@@ -627,13 +632,13 @@ __device__ __forceinline__ u32x4 load4(const uint32_t *p) {
 }
 
 // Open-addressing hash of the universe U in LDS, used while the rows are built:
-// slot = (id & ~0xfff) | (position + 1), 0 = empty.  The 20 tag bits reject
+// slot = (id & ~0x1fff) | (position + 1), 0 = empty.  The 19 tag bits reject
 // almost every foreign id without touching U.
 __device__ __forceinline__ uint32_t clq_hash(int32_t id, int shift) { return ((uint32_t)id * 2654435761u) >> shift; }
 
 __device__ __forceinline__ void clq_hash_insert(uint32_t *tab, uint32_t mask, int shift, int32_t id, int pos) {
     uint32_t s = clq_hash(id, shift);
-    const uint32_t val = ((uint32_t)id & ~0xfffu) | (uint32_t)(pos + 1);
+    const uint32_t val = ((uint32_t)id & ~0x1fffu) | (uint32_t)(pos + 1);
     while (atomicCAS(tab + s, 0u, val) != 0u) s = (s + 1) & mask;
 }
 
@@ -644,8 +649,8 @@ __device__ __forceinline__ int clq_hash_find(const uint32_t *tab, uint32_t mask,
     for (;;) {
         uint32_t x = tab[s];
         if (x == 0u) return -1;
-        if (((x ^ (uint32_t)id) & ~0xfffu) == 0u) {
-            int pos = (int)(x & 0xfffu) - 1;
+        if (((x ^ (uint32_t)id) & ~0x1fffu) == 0u) {
+            int pos = (int)(x & 0x1fffu) - 1;
             if (U[pos] == id) return pos;
         }
         s = (s + 1) & mask;
@@ -928,35 +933,25 @@ __global__ void k_sum_slots(const unsigned long long *slots, int n, unsigned lon
 // one of them by where j and l lie.
 //
 // Rows buffer, per root (32-bit words): d <= 1024: rows[i][W0], W0 = words of
-// d bits rounded up to 4.  d > 1024: tile 0 rows[i][32] for i < 1024, then at
-// word 1024*32 tile 1 rows[i][W1] for every i, W1 = words of d-1024 bits
-// rounded up to 4.
+// d bits rounded up to 4.  d > 1024: up to four column tiles of 1024 bits,
+// tile t stored as rows[i][W_t] for i < min(d, 1024 (t + 1)) (see big_off).
+// The count runs over the tile pairs (a, b), a <= b: j in tile a, l in tile b.
 
-struct BigLayout {
-    int d, W0, W1;
-    int t1_off;  // word offset of tile 1 inside the root's region
-};
-
-__device__ __forceinline__ BigLayout big_layout(int d) {
-    BigLayout b;
-    b.d = d;
-    if (d <= 1024) {
-        b.W0 = (((d + 31) >> 5) + 3) & ~3;
-        b.W1 = 0;
-        b.t1_off = 0;
-    } else {
-        b.W0 = 32;
-        b.W1 = (((d - 1024 + 31) >> 5) + 3) & ~3;
-        b.t1_off = 1024 * 32;
-    }
-    return b;
+// Column tiles of one root's rows: tile t covers columns [1024 t, min(d, 1024 (t + 1))) and holds the
+// rows that can have bits there, i < min(d, 1024 (t + 1)); every tile but the last is 1024 x 32 words
+// per 1024 rows, so tile t starts 32768 * t (t + 1) / 2 words into the root's region.
+__device__ __forceinline__ int big_tiles(int d) { return d <= 1024 ? 1 : (d + 1023) >> 10; }
+__device__ __forceinline__ int big_rows(int d, int t) { return min(d, 1024 * (t + 1)); }
+__device__ __forceinline__ int big_words(int d, int t) {
+    return (((big_rows(d, t) - 1024 * t + 31) >> 5) + 3) & ~3;
 }
+__device__ __forceinline__ int64_t big_off(int t) { return (int64_t)32768 * (t * (t + 1) / 2); }
 
 #define BIG_ROWS_PER_WG 64
 
 // grid = nroots * (dcap / 64) workgroups of 256 threads; workgroup (ri, rb)
 // builds rows [64*rb, 64*rb + 64) of root ri.  LDS (words): U[dcap] | Dp[dcap]
-// | hash[2*dcap] | stage[4][64].  K == 3 only counts the bits (triangles).
+// | hash[2*dcap] | stage[4][128].  K == 3 only counts the bits (triangles).
 template <int K>
 __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
                                                    int probe_bias, uint32_t *rows_buf, int64_t stride_words,
@@ -977,8 +972,8 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
     int32_t *U = (int32_t *)smem;
     uint32_t *Dp = smem + dcap;
     uint32_t *htab = smem + 2 * dcap;
-    uint32_t *stage = smem + 4 * dcap + wave * 64;
-    const BigLayout lay = big_layout(d);
+    uint32_t *stage = smem + 4 * dcap + wave * 128;
+    const int T = big_tiles(d);
     uint32_t *region = rows_buf + ri * stride_words;
 
     int hbits = 1;
@@ -995,7 +990,7 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
     }
     __syncthreads();
 
-    const int Wall = lay.W1 ? 32 + lay.W1 : lay.W0;  // words of a whole row in the stage
+    const int Wall = 32 * (T - 1) + big_words(d, T - 1);  // words of a whole row in the stage
     uint64_t bytes = 0, bytes3 = 0, tri = 0;  // bytes3: level 3, the work of the count kernel on these rows
     const int i_end = min(d, i0 + BIG_ROWS_PER_WG);
     for (int i = i0 + wave; i < i_end; i += 4) {
@@ -1034,6 +1029,7 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
             }
         } else {
             stage[lane] = 0;
+            stage[GPM_WAVE + lane] = 0;
             wave_lds_sync();
             const int64_t vb = mid[v], ve = off[v + 1];
             for (int64_t p0 = vb; p0 < ve; p0 += 4 * GPM_WAVE) {  // four list reads in flight per lane
@@ -1057,11 +1053,9 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
         }
         if (K != 3) {
             wave_lds_sync();
-            if (lay.W1 == 0) {
-                if (lane < lay.W0) region[(size_t)i * lay.W0 + lane] = stage[lane];
-            } else {
-                if (i < 1024 && lane < 32) region[(size_t)i * 32 + lane] = stage[lane];
-                if (lane < lay.W1) region[(size_t)lay.t1_off + (size_t)i * lay.W1 + lane] = stage[32 + lane];
+            for (int t = 0; t < T; ++t) {
+                const int Wt = big_words(d, t);
+                if (i < big_rows(d, t) && lane < Wt) region[big_off(t) + (int64_t)i * Wt + lane] = stage[32 * t + lane];
             }
         }
         wave_lds_sync();
@@ -1087,42 +1081,30 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
                                                     unsigned long long *n_matches) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
-    const int phases = dcap > 1024 ? 3 : 1;
+    const int tcap = dcap > 1024 ? dcap >> 10 : 1;  // column tiles a root of this class can have
+    const int phases = tcap * (tcap + 1) / 2;        // tile pairs (a, b), a <= b
     const int64_t ri = blockIdx.x / (phases * SEG);
     const int ph = (int)(blockIdx.x / SEG) % phases;
     const int seg = (int)(blockIdx.x % SEG);
     if (ri >= nroots) return;
     const int32_t u = roots[ri];
     const int d = (int)(g.off[0][u + 1] - g.mid[0][u]);
-    const BigLayout lay = big_layout(d);
-    if (lay.W1 == 0 && ph > 0) return;
+    int ta = 0, tb = ph;  // the ph-th pair in the order (0,0) (0,1) .. (0,tcap-1) (1,1) ..
+    while (tb >= tcap - ta) {
+        tb -= tcap - ta;
+        ta++;
+    }
+    tb += ta;
+    if (tb >= big_tiles(d)) return;
     const uint32_t *region = rows_buf + ri * stride_words;
 
-    // what this task holds in LDS and walks
-    int j_lo, j_hi, Wt, i_hi;       // rows j of the row tile, words per row of the column tile, rows i walked
-    const uint32_t *tile_rows;      // rows j_lo.. of the column tile, Wt words each
-    const uint32_t *jsrc;           // row i's words over the row tile's positions (list of j)
-    int Wj;
-    const uint32_t *xsrc;           // row i's words over the column tile
-    if (lay.W1 == 0) {
-        j_lo = 0, j_hi = d, Wt = lay.W0, i_hi = d;
-        tile_rows = jsrc = xsrc = region;
-        Wj = lay.W0;
-    } else if (ph == 0) {           // j, l in tile 0
-        j_lo = 0, j_hi = 1024, Wt = 32, i_hi = 1024;
-        tile_rows = jsrc = xsrc = region;
-        Wj = 32;
-    } else if (ph == 1) {           // j in tile 0, l in tile 1
-        j_lo = 0, j_hi = 1024, Wt = lay.W1, i_hi = 1024;
-        tile_rows = xsrc = region + lay.t1_off;
-        jsrc = region;
-        Wj = 32;
-    } else {                        // j, l in tile 1
-        j_lo = 1024, j_hi = d, Wt = lay.W1, i_hi = d;
-        tile_rows = region + lay.t1_off + (size_t)1024 * lay.W1;
-        jsrc = xsrc = region + lay.t1_off;
-        Wj = lay.W1;
-    }
+    // what this task holds in LDS and walks: the rows j of tile a restricted to the columns of tile b;
+    // rows i < j_hi are walked, their bits over tile a list the j, their words over tile b are ANDed
+    const int j_lo = 1024 * ta, j_hi = big_rows(d, ta), i_hi = j_hi;
+    const int Wt = big_words(d, tb), Wj = big_words(d, ta);
+    const uint32_t *xsrc = region + big_off(tb);                 // row i's words over the column tile
+    const uint32_t *jsrc = region + big_off(ta);                 // row i's words over the row tile's positions
+    const uint32_t *tile_rows = xsrc + (size_t)j_lo * Wt;        // rows j_lo.. of the column tile
     uint16_t *J = (uint16_t *)smem + wave * 1024;
     uint32_t *tile = smem + NW * 512;
     {

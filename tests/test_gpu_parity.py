@@ -225,7 +225,8 @@ def complete_graph(n):
 
 
 @pytest.mark.parametrize("n,pname", [(70, "clique4"), (70, "clique6"), (300, "triangle"), (300, "clique4"),
-                                     (300, "clique5"), (1100, "clique4"), (1300, "triangle")])
+                                     (300, "clique5"), (1100, "clique4"), (1300, "triangle"), (2600, "clique4"),
+                                     (3300, "triangle")])
 def test_cliques_in_complete_graphs_closed_form(n, pname):
     """K_n holds n!/(n-k)! embeddings of the k-clique; n = 70 / 300 / 1100+ put the roots in the
     one-wave, LDS-row and global-row classes of the bitmap kernel."""
@@ -264,6 +265,35 @@ def test_two_path_counting_of_four_cycles_equals_the_generic_path(monkeypatch):
         assert m.findMatches(count_only=True) == want, chunks
     st = m.stats()
     assert st.kernel_launches[5] > 0  # GPM_KIND_CYCLE4
+    m.close()
+
+
+@pytest.mark.parametrize("hub_rows", [None, "0"], ids=["hub_matrix", "hashed_lists"])
+def test_universes_of_up_to_four_column_tiles(hub_rows, monkeypatch):
+    """Complete 5-partite graph with parts of 800: |N+| runs up to 3200, so the rows of a root span up
+    to four column tiles of 1024 bits and the count runs over all ten tile pairs.  Every choice of k
+    parts and one vertex in each is a k-clique."""
+    if hub_rows is not None:
+        monkeypatch.setenv("GPM_HUB_ROWS", hub_rows)
+    parts, size = 5, 800
+    n = parts * size
+    v = np.arange(n)
+    a = np.repeat(v, n)
+    b = np.tile(v, n)
+    keep = (a // size) != (b // size)
+    a, b = a[keep], b[keep]
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(off, a + 1, 1)
+    m = binding.Matcher(1)
+    m.upload(n, np.cumsum(off), b.astype(np.int32))
+    for pname, k in (("triangle", 3), ("clique4", 4)):
+        m.set_pattern(gen.PATTERNS[pname])
+        want = 1
+        for i in range(k):
+            want *= (parts - i) * size  # ordered choice of distinct parts, one vertex in each
+        assert m.findMatches(count_only=True) == want, pname
+        st = m.stats()
+        assert st.kernel_launches[3] > 0 and st.kernel_launches[1] == 0  # build kernel used, nothing left to the generic path
     m.close()
 
 
