@@ -116,12 +116,53 @@ int buildPlan(const Pattern *p, int flags, gpm_plan *plan, char *err, int errLen
     if (makeGraphOrdering(p, ordering, parents) != 0)
         return planFail(err, errLen, "pattern is not connected from vertex 1");
 
+    /* The set of matches does not depend on the order in which the pattern
+     * vertices are bound, only the work does.  Unless the reference's order is
+     * asked for, leaves (vertices with a single neighbour) are bound last --
+     * they multiply the partial matches without constraining anything, and at
+     * the end they are counted in closed form -- and a search that would start
+     * at a leaf starts at that leaf's neighbour instead.  Every other vertex
+     * keeps its place in the reference's depth-first numbering. */
+    const char *orderEnv = getenv("GPM_PLAN_ORDER");
+    int keepReference = (flags & PLAN_REFERENCE_ORDER) || (orderEnv && strcmp(orderEnv, "reference") == 0);
+    int nbrs[MAX_MATCH_SIZE] = {0}, someNbr[MAX_MATCH_SIZE];
+    for (int v = 0; v < P; ++v) {
+        unsigned seen = 0;
+        someNbr[v] = -1;
+        for (int j = 0; j < p->outDegrees[v]; ++j)
+            if (p->outEdges[v][j] != v) seen |= 1u << p->outEdges[v][j];
+        for (int j = 0; j < p->inDegrees[v]; ++j)
+            if (p->inEdges[v][j] != v) seen |= 1u << p->inEdges[v][j];
+        for (int w = 0; w < P; ++w)
+            if (seen >> w & 1u) {
+                nbrs[v]++;
+                if (someNbr[v] < 0) someNbr[v] = w;
+            }
+    }
+    int num[MAX_MATCH_SIZE] = {0};
+    int32_t par0[MAX_MATCH_SIZE];
+    int root = (!keepReference && P > 2 && nbrs[0] == 1) ? someNbr[0] : 0;
+    if (numberFrom(p, root, -1, 1, num, par0, 0) != P)
+        return planFail(err, errLen, "pattern is not connected from vertex 1");
+    int seq[MAX_MATCH_SIZE], viaIn[MAX_MATCH_SIZE];
+    for (int v = 0; v < P; ++v) {
+        seq[abs(num[v]) - 1] = v;
+        viaIn[v] = num[v] < 0;
+    }
     int levelOf[MAX_MATCH_SIZE];
     plan->n_levels = P;
     plan->n_aut = 1;
-    for (int k = 0; k < P; ++k) {
-        plan->order[k] = abs(ordering[k + 1]) - 1;
-        levelOf[plan->order[k]] = k;
+    {
+        int k = 0;
+        for (int pass = 0; pass < 2; ++pass) /* pass 0: the root and the inner vertices, pass 1: the leaves */
+            for (int i = 0; i < P; ++i) {
+                int v = seq[i];
+                int leaf = !keepReference && v != root && nbrs[v] == 1;
+                if (leaf == pass) {
+                    plan->order[k] = v;
+                    levelOf[v] = k++;
+                }
+            }
     }
     int symData = (flags & PLAN_SYMMETRIC_DATA) != 0;
 
@@ -152,8 +193,8 @@ int buildPlan(const Pattern *p, int flags, gpm_plan *plan, char *err, int errLen
             plan->src_level[0] = -1;
             continue;
         }
-        int parent = parents[pv + 1] - 1;
-        int srcDir = ordering[k + 1] < 0 ? 1 : 0; /* reached through an in-edge: walk the parent's in-list */
+        int parent = par0[pv];
+        int srcDir = viaIn[pv]; /* reached through an in-edge: walk the parent's in-list */
         plan->src_level[k] = levelOf[parent];
         plan->src_dir[k] = symData ? 0 : srcDir;
         /* every bound pattern neighbour t constrains the candidate c:

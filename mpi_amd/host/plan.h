@@ -21,7 +21,9 @@ int makeGraphOrdering(const Pattern *p, int32_t ordering[MAX_MATCH_SIZE + 1], in
 enum {
     PLAN_SYMMETRIC_DATA = 1, /* in-lists equal out-lists: every constraint uses the out-CSR */
     PLAN_BREAK_SYMMETRY = 2, /* add ordering bounds from the pattern's automorphisms (simple data graphs only) */
-    PLAN_DEGREE_FILTER = 4   /* require deg(c) >= deg_P(p) (simple data graphs only) */
+    PLAN_DEGREE_FILTER = 4,  /* require deg(c) >= deg_P(p) (simple data graphs only) */
+    PLAN_REFERENCE_ORDER = 8 /* bind the pattern vertices in the reference's depth-first order (also GPM_PLAN_ORDER=reference);
+                              * default: same order with the leaves moved to the end */
 };
 
 /* Fill *plan for pattern p.  On success plan->aut points to a malloc'd table

@@ -139,11 +139,12 @@ VARIANTS = [
     {"symbreak": True, "env": {"GPM_NO_CLIQUE": "1", "GPM_NO_REUSE": "1"}},
     {"symbreak": True, "env": {"GPM_NO_TWIN": "1", "GPM_NO_CYCLE4": "1"}},
     {"symbreak": True, "env": {"GPM_NO_LABEL_SEGMENTS": "1"}},
+    {"symbreak": True, "env": {"GPM_PLAN_ORDER": "reference"}},
 ]
 VAR_SPECS = [g for g in GOLDEN if g["name"] in (
     "rand9_sym_clique4", "rand9_sym_cycle4", "rand9_dir_tree5_dir", "rand40_dir_rev4", "rand40_dir_k4_dag",
     "rmat8_triangle", "rmat8_clique4", "rmat8_cycle4", "rmat8_house", "rmat8_clique5", "skew8_k6_minus_e",
-    "skew9_k6_minus_pm", "rmat10_cycle4",
+    "skew9_k6_minus_pm", "rmat10_cycle4", "rand9_sym_path3", "rand9_dir_path3", "rand40_dir_tree5_dir",
     "plaw9_tree5_labelled4", "er10k_triangle")]
 
 
@@ -349,9 +350,13 @@ def test_large_universes_of_the_clique_kernel(env, monkeypatch):
 @pytest.mark.parametrize("pname", ["path3", "star4", "path4", "tree5", "house", "diamond"])
 @pytest.mark.parametrize("symbreak", [True, False])
 @pytest.mark.parametrize("labelled", [False, True])
-def test_leaf_levels_counted_in_closed_form(pname, symbreak, labelled, monkeypatch):
+@pytest.mark.parametrize("plan_order", ["leaves_last", "reference"])
+def test_leaf_levels_counted_in_closed_form(pname, symbreak, labelled, plan_order, monkeypatch):
     """Patterns that end in leaf vertices: the closed-form counts equal the oracle's enumeration
-    and the count obtained with the closed forms switched off."""
+    and the count obtained with the closed forms switched off, with the leaves bound last (the
+    planner's default) and in the reference's depth-first order."""
+    if plan_order == "reference":
+        monkeypatch.setenv("GPM_PLAN_ORDER", "reference")
     n, s, d = util.build_graph({"graph": "plaw", "n": 512, "avg_deg": 6, "seed": 3})
     P = gen.PATTERNS[pname][0]
     dl = pl = None
