@@ -298,6 +298,27 @@ def test_universes_of_up_to_four_column_tiles(hub_rows, monkeypatch):
     m.close()
 
 
+def test_directed_acyclic_clique_equals_the_undirected_count():
+    """Keep every edge of a symmetric graph in one direction only (low id -> high id): the acyclic
+    4-clique pattern then has exactly one embedding per undirected 4-clique, i.e. 1/24 of the
+    embeddings of the undirected pattern -- the directed level-by-level path (both CSR directions)
+    against the bitmap path."""
+    n, s, d = util.build_graph({"graph": "rmat", "scale": 12, "ef": 8, "seed": 1})
+    m = binding.Matcher(1)
+    upload(m, n, s, d)
+    m.set_pattern(gen.PATTERNS["clique4"])
+    undirected = m.findMatches(count_only=True)
+    m.close()
+    keep = np.asarray(d) > np.asarray(s)
+    m = binding.Matcher(1)
+    upload(m, n, np.asarray(s)[keep], np.asarray(d)[keep])
+    m.set_pattern(gen.PATTERNS["k4_dag"])
+    assert m.findMatches(count_only=True) * 24 == undirected
+    m.set_pattern(gen.PATTERNS["tri_dir"])
+    assert m.findMatches(count_only=True) == 0  # no directed cycle in an acyclic orientation
+    m.close()
+
+
 def test_clique_kernel_equals_generic_path(monkeypatch):
     """Bitmap kernel vs level-by-level path on R-MAT scale 13, K = 3..6, incl. a mixed split of the roots."""
     n, s, d = util.build_graph({"graph": "rmat", "scale": 13, "ef": 8, "seed": 3})
