@@ -192,12 +192,15 @@ __device__ __forceinline__ bool accept(const GraphView &g, const LevelPlan &lv, 
                                        int skip_cons = -1) {
     for (int t = 0; t < k; ++t)
         if (m[t] == c) return false;
-    if (!vertex_ok(g, lv, c)) return false;
+    if (lv.label >= 0 && g.label[c] != (uint8_t)lv.label) return false;  // one byte, very selective: first
     for (int j = 0; j < lv.n_cons; ++j) {
         bool in = j == skip_cons ? in_list(g, lv.src_dir, lv.src_part, m[lv.src_level], c)
                                  : in_list(g, lv.cons_dir[j], lv.cons_part[j], m[lv.cons_level[j]], c);
         if (!in) return false;
     }
+    // the degree filter rarely rejects a vertex that passed the membership tests: last
+    if (lv.min_out > 0 && g.off[0][c + 1] - g.off[0][c] < lv.min_out) return false;
+    if (lv.min_in > 0 && g.off[1][c + 1] - g.off[1][c] < lv.min_in) return false;
     return true;
 }
 
