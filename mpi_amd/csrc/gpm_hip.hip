@@ -678,9 +678,22 @@ extern "C" int gpm_hip_upload_graph(gpm_ctx *ctx, int32_t n, const int64_t *out_
     ctx->have_plan = false;
     ctx->chunks_valid = false;
     uint32_t flags = 0;
-    for (auto &d : ctx->devs) {
-        int rc = upload_one(d, n, out_off, out_adj, in_off, in_adj, labels, &flags);
+    if (ctx->devs.size() == 1) {
+        int rc = upload_one(ctx->devs[0], n, out_off, out_adj, in_off, in_adj, labels, &flags);
         if (rc != GPM_OK) return rc;
+    } else {  // every GPU copies and prepares its replica at the same time
+        std::vector<std::thread> threads;
+        std::vector<uint32_t> dev_flags(ctx->devs.size(), 0);
+        for (size_t i = 0; i < ctx->devs.size(); ++i)
+            threads.emplace_back([&, i] {
+                DevState &d = ctx->devs[i];
+                d.rc = upload_one(d, n, out_off, out_adj, in_off, in_adj, labels, &dev_flags[i]);
+                if (d.rc) d.err = gpm_hip_last_error();
+            });
+        for (auto &t : threads) t.join();
+        for (auto &d : ctx->devs)
+            if (d.rc) return fail(d.rc, "%s", d.err.c_str());
+        flags = dev_flags[0];
     }
     int64_t max_out = 0, max_in = 0;
     for (int32_t v = 0; v < n; ++v) {
