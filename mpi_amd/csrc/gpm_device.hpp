@@ -115,8 +115,9 @@ __device__ __forceinline__ bool from_segment(const GraphView &g, const LevelPlan
 // Candidate range of one level for the partial match m: positions [b, e) of
 // `arr`, the source list (or its segment of the level's label) cut down by the
 // ordering bounds (c > every lower bound, c < every upper bound).
+// Bounds that refer to level `skip_level` are left out (that vertex is not bound yet).
 __device__ __forceinline__ void source_range(const GraphView &g, const LevelPlan &lv, const int32_t *m, int64_t &b,
-                                             int64_t &e, const int32_t *&arr) {
+                                             int64_t &e, const int32_t *&arr, int skip_level = -1) {
     if (from_segment(g, lv)) {
         const int32_t v = m[lv.src_level];
         arr = g.adjL;
@@ -126,8 +127,10 @@ __device__ __forceinline__ void source_range(const GraphView &g, const LevelPlan
         b = g.off[0][v] + seg[0];
         e = g.off[0][v] + seg[1];
         int32_t lo = lv.src_part == PART_ABOVE ? v : -1, hi = lv.src_part == PART_BELOW ? v : INT32_MAX;
-        for (int j = 0; j < lv.n_lower; ++j) lo = max(lo, m[lv.lower_level[j]]);
-        for (int j = 0; j < lv.n_upper; ++j) hi = min(hi, m[lv.upper_level[j]]);
+        for (int j = 0; j < lv.n_lower; ++j)
+            if (lv.lower_level[j] != skip_level) lo = max(lo, m[lv.lower_level[j]]);
+        for (int j = 0; j < lv.n_upper; ++j)
+            if (lv.upper_level[j] != skip_level) hi = min(hi, m[lv.upper_level[j]]);
         if (lo >= 0) b = lower_bound_g(arr, b, e, lo + 1);
         if (hi != INT32_MAX) e = lower_bound_g(arr, b, e, hi);
         return;
@@ -135,14 +138,16 @@ __device__ __forceinline__ void source_range(const GraphView &g, const LevelPlan
     arr = g.adj[lv.src_dir];
     list_range(g, lv.src_dir, lv.src_part, m[lv.src_level], b, e);
     if (lv.n_lower && !lv.lower_is_src) {
-        int32_t lo = m[lv.lower_level[0]];
-        for (int j = 1; j < lv.n_lower; ++j) lo = max(lo, m[lv.lower_level[j]]);
-        b = lower_bound_g(g.adj[lv.src_dir], b, e, lo + 1);
+        int32_t lo = -1;
+        for (int j = 0; j < lv.n_lower; ++j)
+            if (lv.lower_level[j] != skip_level) lo = max(lo, m[lv.lower_level[j]]);
+        if (lo >= 0) b = lower_bound_g(g.adj[lv.src_dir], b, e, lo + 1);
     }
     if (lv.n_upper) {
-        int32_t hi = m[lv.upper_level[0]];
-        for (int j = 1; j < lv.n_upper; ++j) hi = min(hi, m[lv.upper_level[j]]);
-        e = lower_bound_g(g.adj[lv.src_dir], b, e, hi);
+        int32_t hi = INT32_MAX;
+        for (int j = 0; j < lv.n_upper; ++j)
+            if (lv.upper_level[j] != skip_level) hi = min(hi, m[lv.upper_level[j]]);
+        if (hi != INT32_MAX) e = lower_bound_g(g.adj[lv.src_dir], b, e, hi);
     }
 }
 

@@ -846,6 +846,7 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
                    same_filters && env_i64("GPM_NO_REUSE", 0) == 0;
         ti.twin = ctx->info.simple && n_extra == 0 && same_list_set(la, lb_rest) && same_bounds && same_filters &&
                   env_i64("GPM_NO_TWIN", 0) == 0;
+        ti.indep = ctx->info.simple && n_extra == 0 && !ti.twin && env_i64("GPM_NO_INDEP", 0) == 0;
         // leaf levels: adjacency to the source is the only requirement besides the label
         const bool closed_ok = ctx->info.simple && ctx->info.symmetric && env_i64("GPM_NO_LEAF", 0) == 0;
         auto leaf = [&](const LevelPlan &X) {

@@ -227,6 +227,8 @@ struct TailInfo {
     int8_t leaf_b;          // level B is a leaf level: counted in closed form per A survivor
     int8_t leaf_pair;       // levels A and B are both leaves off earlier vertices: closed form per row
     int8_t pair_same_set;   // ... and draw from the same candidate set (same source, same label)
+    int8_t indep;           // level B has no list of the A vertex: its candidate set does not depend on a, so
+                            // it is walked once per staged set and paired with it (|A||B| minus the clashes)
     int8_t twin;            // level B has exactly level A's lists, bounds and filters and no list of the A
                             // vertex: the two draw from one survivor set S, counted as pairs of S
 };
@@ -361,6 +363,47 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
                         c -= 1;
                     if (c > 0) cnt += (uint64_t)c;
                     bytes += 4ull * (uint64_t)(L + 1) + 4ull * (uint64_t)(g.off[0][s + 1] - g.off[0][s]);
+                }
+                n_staged = 0;
+                wave_lds_sync();
+                continue;
+            }
+            if (ti.indep && n_staged == 0) continue;
+            if (ti.indep) {
+                // level B does not depend on a: walk its candidates once and pair each with the staged
+                // (ascending) survivors of level A that it may go with
+                int wb = -1;
+                int64_t b2, e2;
+                const int32_t *barr;
+                source_range(g, lb, m, b2, e2, barr, L);
+                for (int j = 0; j < lb.n_cons; ++j) {
+                    int64_t cb, ce;
+                    list_range(g, lb.cons_dir[j], lb.cons_part[j], m[lb.cons_level[j]], cb, ce);
+                    if (ce - cb < e2 - b2) {
+                        b2 = cb;
+                        e2 = ce;
+                        wb = j;
+                    }
+                }
+                int32_t lo2 = -1, hi2 = INT32_MAX;
+                if (wb >= 0) {
+                    barr = g.adj[lb.cons_dir[wb]];
+                    for (int j = 0; j < lb.n_lower; ++j)
+                        if (lb.lower_level[j] != L) lo2 = max(lo2, m[lb.lower_level[j]]);
+                    for (int j = 0; j < lb.n_upper; ++j)
+                        if (lb.upper_level[j] != L) hi2 = min(hi2, m[lb.upper_level[j]]);
+                }
+                for (int64_t i2 = b2 + lane; i2 < e2; i2 += GPM_WAVE) {
+                    const int32_t c2 = barr[i2];
+                    if (!(c2 > lo2 && c2 < hi2 && accept(g, lb, m, L, c2, wb))) continue;
+                    const int p = lower_bound_s(staged, 0, n_staged, c2);  // survivors below c2
+                    const int same = p < n_staged && staged[p] == c2;
+                    cnt += ti.b_lower_is_a ? (uint32_t)p : ti.b_upper_is_a ? (uint32_t)(n_staged - p - same)
+                                                                          : (uint32_t)(n_staged - same);
+                }
+                if (lane == 0) {  // level B per survivor: its ids and one pass over B's lists (none owned by a)
+                    m[L] = staged[0];
+                    bytes += (uint64_t)n_staged * level_bytes(g, lb, m, L + 1);
                 }
                 n_staged = 0;
                 wave_lds_sync();

@@ -140,6 +140,8 @@ VARIANTS = [
     {"symbreak": True, "env": {"GPM_NO_TWIN": "1", "GPM_NO_CYCLE4": "1"}},
     {"symbreak": True, "env": {"GPM_NO_LABEL_SEGMENTS": "1"}},
     {"symbreak": True, "env": {"GPM_PLAN_ORDER": "reference"}},
+    {"symbreak": True, "env": {"GPM_NO_INDEP": "1"}},
+    {"symbreak": False, "env": {"GPM_NO_INDEP": "1"}},
 ]
 VAR_SPECS = [g for g in GOLDEN if g["name"] in (
     "rand9_sym_clique4", "rand9_sym_cycle4", "rand9_dir_tree5_dir", "rand40_dir_rev4", "rand40_dir_k4_dag",
