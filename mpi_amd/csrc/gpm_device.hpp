@@ -52,6 +52,8 @@ struct LevelPlan {
     int8_t cons_level[GPM_MAXC], cons_dir[GPM_MAXC], cons_part[GPM_MAXC];
     int8_t lower_level[GPM_MAXC], upper_level[GPM_MAXC];
     int8_t lower_is_src;  // the only lower bound is the source owner (range = PART_ABOVE, no search)
+    uint16_t src_adj;     // levels whose pattern vertex is adjacent to this level's source vertex: their data
+                          // vertices are known neighbours of the source (symmetric graphs), no search needed
     int32_t label, min_out, min_in;
 };
 
@@ -240,7 +242,9 @@ __device__ __forceinline__ int64_t leaf_count(const GraphView &g, const LevelPla
                               : g.off[0][s + 1] - g.off[0][s];
     for (int t = 0; t < k; ++t) {
         const int32_t x = m[t];
-        if (x != s && (lv.label < 0 || g.label[x] == (uint8_t)lv.label) && in_list(g, 0, PART_FULL, s, x)) c -= 1;
+        if (x != s && (lv.label < 0 || g.label[x] == (uint8_t)lv.label) &&
+            (((lv.src_adj >> t) & 1u) || in_list(g, 0, PART_FULL, s, x)))
+            c -= 1;
     }
     return c;
 }

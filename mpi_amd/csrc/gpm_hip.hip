@@ -812,6 +812,20 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
         lv.lower_is_src = lv.n_lower == 1 && lv.lower_level[0] == lv.src_level;
     }
 
+    // pattern adjacency between levels, for the closed-form leaf counts
+    if (ctx->info.symmetric) {
+        uint16_t adjl[GPM_MAXP] = {};
+        for (int k = 1; k < P; ++k) {
+            const LevelPlan &lv = pv.lv[k];
+            adjl[k] |= (uint16_t)(1u << lv.src_level);
+            adjl[lv.src_level] |= (uint16_t)(1u << k);
+            for (int j = 0; j < lv.n_cons; ++j) {
+                adjl[k] |= (uint16_t)(1u << lv.cons_level[j]);
+                adjl[lv.cons_level[j]] |= (uint16_t)(1u << k);
+            }
+        }
+        for (int k = 1; k < P; ++k) pv.lv[k].src_adj = adjl[pv.lv[k].src_level];
+    }
     // relation between the last two levels (fused intersection kernel)
     TailInfo &ti = ctx->ti;
     memset(&ti, 0, sizeof ti);

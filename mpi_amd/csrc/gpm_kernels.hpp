@@ -359,7 +359,8 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
                     const int32_t a = staged[ia];
                     const int32_t s = lb.src_level == L ? a : m[lb.src_level];
                     int64_t c = leaf_count(g, lb, m, L, s);
-                    if (a != s && (lb.label < 0 || g.label[a] == (uint8_t)lb.label) && in_list(g, 0, PART_FULL, s, a))
+                    if (a != s && (lb.label < 0 || g.label[a] == (uint8_t)lb.label) &&
+                        (((lb.src_adj >> L) & 1u) || in_list(g, 0, PART_FULL, s, a)))
                         c -= 1;
                     if (c > 0) cnt += (uint64_t)c;
                     bytes += 4ull * (uint64_t)(L + 1) + 4ull * (uint64_t)(g.off[0][s + 1] - g.off[0][s]);
@@ -509,7 +510,8 @@ __global__ void k_leaf_pair(GraphView g, PlanView pl, TailInfo ti, const int32_t
         const int32_t *m = rows + r * L;
         const LevelPlan &la = pl.lv[L], &lb = pl.lv[L + 1];
         const int32_t sa = m[la.src_level], sb = m[lb.src_level];
-        const int64_t ca = leaf_count(g, la, m, L, sa), cb = leaf_count(g, lb, m, L, sb);
+        const int64_t ca = leaf_count(g, la, m, L, sa);
+        const int64_t cb = ti.pair_same_set ? ca : leaf_count(g, lb, m, L, sb);  // same source, same label: same set
         if (ca > 0 && cb > 0) cnt = (uint64_t)(ca * cb - (ti.pair_same_set ? ca : 0));
         const uint64_t la_len = (uint64_t)(g.off[0][sa + 1] - g.off[0][sa]);
         const uint64_t lb_len = (uint64_t)(g.off[0][sb + 1] - g.off[0][sb]);
