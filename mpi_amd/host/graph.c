@@ -238,13 +238,130 @@ static Pattern *patternFromSection(const Section *sec, char *err, int errLen) {
     return p;
 }
 
+/* ---- side-car cache of the parsed data graph ------------------------------
+ *
+ * With GPM_CSR_CACHE=1 the CSR of the data-graph section is kept next to the
+ * input as "<input>.gpmcsr" (or under $GPM_CSR_CACHE_DIR) and read back on the
+ * next run when the input file still has the same size and modification time;
+ * the pattern and the labels trailer are always parsed from the text.  The
+ * benchmark runs the same multi-gigabyte input at 1, 2, 4 and 8 GPUs. */
+
+typedef struct {
+    char magic[8]; /* "GPMCSR1\0" */
+    int64_t inputSize, inputMtimeSec, inputMtimeNsec;
+    int64_t nodesCount, edgesCount;
+    int64_t restOffset, restLine; /* where the pattern section starts in the text, lines before it */
+    int32_t symmetric, simple;
+} CacheHeader;
+
+static int cachePath(const char *input, char *out, size_t outLen) {
+    const char *on = getenv("GPM_CSR_CACHE");
+    if (!on || !*on || strcmp(on, "0") == 0) return 0;
+    const char *dir = getenv("GPM_CSR_CACHE_DIR");
+    if (dir && *dir) {
+        const char *base = strrchr(input, '/');
+        base = base ? base + 1 : input;
+        return snprintf(out, outLen, "%s/%s.gpmcsr", dir, base) < (int)outLen;
+    }
+    return snprintf(out, outLen, "%s.gpmcsr", input) < (int)outLen;
+}
+
+static int readAll(FILE *f, void *dst, size_t bytes) {
+    char *p = dst;
+    while (bytes) { /* a single fread of many GiB is fine on glibc, but keep the requests moderate */
+        size_t want = bytes < ((size_t)1 << 30) ? bytes : ((size_t)1 << 30);
+        if (fread(p, 1, want, f) != want) return -1;
+        p += want;
+        bytes -= want;
+    }
+    return 0;
+}
+
+static Graph *cacheLoad(const char *path, const struct stat *in, int64_t *restOffset, int64_t *restLine) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return NULL;
+    CacheHeader h;
+    Graph *g = NULL;
+    if (fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "GPMCSR1", 8) == 0 && h.inputSize == (int64_t)in->st_size &&
+        h.inputMtimeSec == (int64_t)in->st_mtim.tv_sec && h.inputMtimeNsec == (int64_t)in->st_mtim.tv_nsec &&
+        h.nodesCount >= 0 && h.nodesCount < INT32_MAX && h.edgesCount >= 0 && h.restOffset <= h.inputSize) {
+        size_t n = (size_t)h.nodesCount, m = (size_t)h.edgesCount;
+        g = safeCalloc(1, sizeof *g);
+        g->nodesCount = (int32_t)n;
+        g->edgesCount = (int64_t)m;
+        g->symmetric = h.symmetric;
+        g->simple = h.simple;
+        g->outOffsets = safeMalloc((n + 1) * sizeof(int64_t));
+        g->outEdges = safeMalloc(m * sizeof(int32_t));
+        g->inOffsets = safeMalloc((n + 1) * sizeof(int64_t));
+        g->inEdges = safeMalloc(m * sizeof(int32_t));
+        int ok = readAll(f, g->outOffsets, (n + 1) * sizeof(int64_t)) == 0 && readAll(f, g->outEdges, m * sizeof(int32_t)) == 0;
+        if (ok && h.symmetric && h.simple) { /* the transpose is the graph itself and is not stored */
+            memcpy(g->inOffsets, g->outOffsets, (n + 1) * sizeof(int64_t));
+            memcpy(g->inEdges, g->outEdges, m * sizeof(int32_t));
+        } else if (ok) {
+            ok = readAll(f, g->inOffsets, (n + 1) * sizeof(int64_t)) == 0 && readAll(f, g->inEdges, m * sizeof(int32_t)) == 0;
+        }
+        ok = ok && g->outOffsets[0] == 0 && g->outOffsets[n] == (int64_t)m && g->inOffsets[n] == (int64_t)m;
+        if (!ok) {
+            freeGraph(g);
+            g = NULL;
+        } else {
+            *restOffset = h.restOffset;
+            *restLine = h.restLine;
+        }
+    }
+    fclose(f);
+    return g;
+}
+
+static void cacheStore(const char *path, const struct stat *in, const Graph *g, int64_t restOffset, int64_t restLine) {
+    char tmp[4200];
+    if (snprintf(tmp, sizeof tmp, "%s.tmp%d", path, (int)getpid()) >= (int)sizeof tmp) return;
+    FILE *f = fopen(tmp, "wb");
+    if (!f) return; /* a cache that cannot be written is not an error */
+    CacheHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "GPMCSR1", 8);
+    h.inputSize = (int64_t)in->st_size;
+    h.inputMtimeSec = (int64_t)in->st_mtim.tv_sec;
+    h.inputMtimeNsec = (int64_t)in->st_mtim.tv_nsec;
+    h.nodesCount = g->nodesCount;
+    h.edgesCount = g->edgesCount;
+    h.restOffset = restOffset;
+    h.restLine = restLine;
+    h.symmetric = g->symmetric;
+    h.simple = g->simple;
+    size_t n = (size_t)g->nodesCount, m = (size_t)g->edgesCount;
+    int ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(g->outOffsets, sizeof(int64_t), n + 1, f) == n + 1 &&
+             fwrite(g->outEdges, sizeof(int32_t), m, f) == m;
+    if (ok && !(g->symmetric && g->simple))
+        ok = fwrite(g->inOffsets, sizeof(int64_t), n + 1, f) == n + 1 && fwrite(g->inEdges, sizeof(int32_t), m, f) == m;
+    ok = fclose(f) == 0 && ok;
+    if (!ok || rename(tmp, path) != 0) remove(tmp);
+}
+
+static int parseInput(const char *buf, int64_t len, Graph *cached, int64_t restOffset, int64_t restLine, Graph **data,
+                      Pattern **pattern, int64_t *restOut, int64_t *lineOut, char *err, int errLen);
+
 int readInputBuffer(const char *buf, int64_t len, Graph **data, Pattern **pattern, char *err, int errLen) {
+    return parseInput(buf, len, NULL, 0, 0, data, pattern, NULL, NULL, err, errLen);
+}
+
+/* Parse the whole input, or with `cached` (the data graph from the side-car
+ * cache) only what follows the data section.  restOut / lineOut receive where
+ * the data section ended. */
+static int parseInput(const char *buf, int64_t len, Graph *cached, int64_t restOffset, int64_t restLine, Graph **data,
+                      Pattern **pattern, int64_t *restOut, int64_t *lineOut, char *err, int errLen) {
     *data = NULL;
     *pattern = NULL;
     Scan s = {buf, buf + len, 0};
     Section ds, ps;
-    Graph *g = NULL;
-    {
+    Graph *g = cached;
+    if (cached) {
+        s.p = buf + restOffset;
+        s.lineNo = restLine;
+    } else {
         /* fast path: well-formed data sections are parsed by several threads */
         Scan t = s;
         int64_t n = 0, lines = 0;
@@ -264,6 +381,8 @@ int readInputBuffer(const char *buf, int64_t len, Graph **data, Pattern **patter
         sectionFree(&ds);
         if (!g) return -1;
     }
+    if (restOut) *restOut = (int64_t)(s.p - buf);
+    if (lineOut) *lineOut = s.lineNo;
     if (scanSection(&s, &ps, err, errLen) != 0) {
         sectionFree(&ps);
         freeGraph(g);
@@ -326,7 +445,13 @@ int readInput(const char *path, Graph **data, Pattern **pattern, char *err, int 
             void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m != MAP_FAILED) {
                 close(fd);
-                int r = readInputBuffer(m, (int64_t)st.st_size, data, pattern, err, errLen);
+                char cpath[4096];
+                int caching = cachePath(path, cpath, sizeof cpath);
+                int64_t rest = 0, restLine = 0;
+                Graph *cached = caching ? cacheLoad(cpath, &st, &rest, &restLine) : NULL;
+                int r = parseInput(m, (int64_t)st.st_size, cached, rest, restLine, data, pattern, &rest, &restLine, err,
+                                   errLen);
+                if (r == 0 && caching && !cached) cacheStore(cpath, &st, *data, rest, restLine);
                 munmap(m, (size_t)st.st_size);
                 return r;
             }

@@ -169,6 +169,36 @@ def test_c_writer_writes_what_the_python_writer_writes(tmp_path):
     assert p.read_text() == text
 
 
+@pytest.mark.parametrize("name", ["plaw9_tree5_labelled4", "rand40_dir_rev4", "rmat10_clique4"])
+def test_csr_cache_gives_the_same_graph(name, tmp_path, monkeypatch):
+    """GPM_CSR_CACHE=1: the second read takes the data graph from the side-car file (pattern and labels
+    still come from the text); a changed input invalidates it."""
+    spec = next(g for g in util.golden_specs() if g["name"] == name)
+    text, _, _ = util.build_input(spec)
+    p = tmp_path / "in.txt"
+    p.write_text(text)
+    cache_dir = tmp_path / "cache"
+    cache_dir.mkdir()
+    first = _read_both_ways(str(p), monkeypatch)[0]
+    monkeypatch.setenv("GPM_CSR_CACHE", "1")
+    monkeypatch.setenv("GPM_CSR_CACHE_DIR", str(cache_dir))
+    stored = _read_both_ways(str(p), monkeypatch)[0]           # parses and stores
+    side_car = cache_dir / "in.txt.gpmcsr"
+    assert side_car.exists()
+    stamp = side_car.stat().st_mtime_ns
+    loaded = _read_both_ways(str(p), monkeypatch)[0]           # loads
+    assert side_car.stat().st_mtime_ns == stamp                # not rewritten: it was used
+    assert first[0] == "ok" and _same(first, stored) and _same(first, loaded)
+    # another graph under the same name: the stale side-car must not be used
+    other = next(g for g in util.golden_specs() if g["name"] == "rmat8_house")
+    p.write_text(util.build_input(other)[0])
+    monkeypatch.delenv("GPM_CSR_CACHE")
+    want = _read_both_ways(str(p), monkeypatch)[0]
+    monkeypatch.setenv("GPM_CSR_CACHE", "1")
+    got = _read_both_ways(str(p), monkeypatch)[0]
+    assert _same(want, got) and not _same(first, got)
+
+
 def test_symmetric_and_simple_flags(tmp_path):
     p = tmp_path / "a.in"
     p.write_text("3\n1 2\n2\n3\n2 1\n1\n3 1\n1\n\n2\n1 1\n2\n")
