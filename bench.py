@@ -72,6 +72,38 @@ def generate(spec, device):
     return spec["n"], *gen.power_law(spec["n"], avg_deg=spec["avg_deg"], seed=spec["seed"], device=device)
 
 
+def cpu_baseline_many_ranks(cfg, ranks, budget_s=150):
+    """The reference under `mpirun -np <ranks>` on the same twin (its vertex partitioning and remote
+    adjacency fetches at work).  Uses the build that keeps the payload of its fire-and-forget sends
+    alive (oracle/ref_isend_fix.c); the untouched reference crashes with three or more ranks."""
+    from tests import util  # noqa: F401  (keeps the import pattern of cpu_baseline)
+    n, off, adj = generate(cfg["twin"], "cpu")
+    s, d = gen.edges_from_csr(*gen.csr_to_numpy(off, adj))
+    ref = os.path.join(ROOT, "oracle", "_ref", "gpm-par-ref-k")
+    mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
+    if "labels" in cfg or not (os.path.exists(ref) and os.path.exists(mpirun)):
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        inp, out = os.path.join(tmp, "in.txt"), os.path.join(tmp, "out.txt")
+        gen.write_input(inp, n, s, d, gen.PATTERNS[cfg["pattern"]])
+        t0 = time.time()
+        try:
+            subprocess.run([mpirun, "-np", str(ranks), ref, inp, out], check=True, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=budget_s)
+        except subprocess.TimeoutExpired:
+            return {"value": None, "unit": "matches/s", "cores": ranks, "kind": "reference",
+                    "sample": f"{describe(cfg['twin'])}, {cfg['pattern']}: did not finish in {budget_s} s"}
+        except Exception as e:  # noqa: BLE001
+            log(f"reference at {ranks} ranks failed: {e!r}")
+            return None
+        dt = time.time() - t0
+        with open(out, "rb") as f:
+            count = sum(chunk.count(b"\n") for chunk in iter(lambda: f.read(1 << 24), b""))
+        return {"value": count / dt, "unit": "matches/s", "cores": ranks, "kind": "reference",
+                "sample": f"{describe(cfg['twin'])} twin of the workload, {cfg['pattern']}, full output to a file, "
+                          f"mpirun -np {ranks}", "matches": count, "seconds": round(dt, 3)}
+
+
 def cpu_baseline(cfg, budget_s=120):
     """The reference (built from its own sources into oracle/_ref) timed under
     `mpirun -np 2` -- one worker, its fastest configuration -- on a scaled-down
@@ -126,6 +158,8 @@ def main():
     ap.add_argument("--scale", type=int, default=None, help="override the R-MAT scale of the configuration")
     ap.add_argument("--pattern", default=None, help="override the pattern of the configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-ranks", type=int, default=0,
+                    help="also time the reference under mpirun -np K (K >= 3) on the twin; off by default, it is slow")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     cfg["graph"] = dict(cfg["graph"])
@@ -258,6 +292,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
+            if args.cpu_ranks >= 3:
+                many = cpu_baseline_many_ranks(cfg, args.cpu_ranks)
+                if many:
+                    line["cpu_baseline_many_ranks"] = many
         print(json.dumps(line), flush=True)
 
     matcher.close()
