@@ -214,19 +214,22 @@ __device__ __forceinline__ bool accept(const GraphView &g, const LevelPlan &lv, 
 // Merge-model bytes of extending one partial match of length k at this
 // level: the match itself plus one pass over every operand list, each list
 // counted at its ordered length.
-__device__ __forceinline__ uint64_t level_bytes(const GraphView &g, const LevelPlan &lv, const int32_t *m, int k) {
+// sub_level >= 0: the vertex of that level is sub_v instead of m[sub_level].
+__device__ __forceinline__ uint64_t level_bytes(const GraphView &g, const LevelPlan &lv, const int32_t *m, int k,
+                                                int sub_level = -1, int32_t sub_v = 0) {
     int64_t b, e;
-    list_range(g, lv.src_dir, lv.src_part, m[lv.src_level], b, e);
+    list_range(g, lv.src_dir, lv.src_part, lv.src_level == sub_level ? sub_v : m[lv.src_level], b, e);
     if (from_segment(g, lv)) {  // only the label's segment of the source list is streamed
         b = e = 0;
         if (lv.label < g.nlab) {
-            const uint32_t *seg = g.labseg + (size_t)m[lv.src_level] * (size_t)(g.nlab + 1) + (size_t)lv.label;
+            const int32_t sv = lv.src_level == sub_level ? sub_v : m[lv.src_level];
+            const uint32_t *seg = g.labseg + (size_t)sv * (size_t)(g.nlab + 1) + (size_t)lv.label;
             e = (int64_t)seg[1] - (int64_t)seg[0];
         }
     }
     uint64_t bytes = 4ull * (uint64_t)k + 4ull * (uint64_t)(e - b);
     for (int j = 0; j < lv.n_cons; ++j) {
-        list_range(g, lv.cons_dir[j], lv.cons_part[j], m[lv.cons_level[j]], b, e);
+        list_range(g, lv.cons_dir[j], lv.cons_part[j], lv.cons_level[j] == sub_level ? sub_v : m[lv.cons_level[j]], b, e);
         bytes += 4ull * (uint64_t)(e - b);
     }
     return bytes;

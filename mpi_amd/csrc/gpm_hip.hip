@@ -61,6 +61,7 @@ enum {  // slots of the per-device counter block (unsigned long long each)
     CTR_TAIL_BYTES = 19,
     CTR_EMIT = 20,
     CTR_CYC_BYTES = 21,       // merge-model bytes of the 4-cycle kernels
+    CTR_OVER = 22,            // [22, 24): partial matches handed back by the two launches of the three-level kernel
     CTR_KIND_BYTES = 40,      // [40, 40 + GPM_KERNEL_KINDS): bytes summed out of the clique slots, per kind
     CTR_CLQ_CLASS0 = 24,  // [24, 29): roots per size class of the clique kernel
     CTR_COUNT = 48
@@ -116,6 +117,8 @@ struct DevState {
     int32_t *F[GPM_MAXP] = {};
     int64_t *beg[GPM_MAXP] = {}, *cnt[GPM_MAXP] = {}, *pref[GPM_MAXP] = {};
     int8_t *wsel[GPM_MAXP] = {};  // which operand list each row walks at the next level
+    int64_t *over_rows = nullptr;  // partial matches the three-level kernel hands back
+    bool no_fuse3 = false;         // ... while they go through the level-by-level path
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     int32_t *emit = nullptr, *emit_host = nullptr;
@@ -167,6 +170,7 @@ struct gpm_ctx {
     std::vector<int8_t> aut;
     PlanView pv{};
     TailInfo ti{};
+    Tail3Info t3{};
     bool use_tail = true;
     int clique_k = 0;  // K when the plan is a K-clique under a total ordering, else 0
     bool use_clique = true;
@@ -327,6 +331,8 @@ static void free_buffers(DevState &d) {
         d.beg[k] = d.cnt[k] = d.pref[k] = nullptr;
     }
     dev_free(d.scan_tmp);
+    dev_free(d.over_rows);
+    d.over_rows = nullptr;
     for (auto &sl : d.slots) {
         dev_free(sl.lists);
         dev_free(sl.counts);
@@ -861,6 +867,25 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
         ti.twin = ctx->info.simple && n_extra == 0 && same_list_set(la, lb_rest) && same_bounds && same_filters &&
                   env_i64("GPM_NO_TWIN", 0) == 0;
         ti.indep = ctx->info.simple && n_extra == 0 && !ti.twin && env_i64("GPM_NO_INDEP", 0) == 0;
+        // three fused levels: level Z = P-3, then twins that need Z's lists, the Z vertex's own list and
+        // possibly lists of further earlier vertices, with no ordering bound between Z and the twins
+        Tail3Info &t3 = ctx->t3;
+        memset(&t3, 0, sizeof t3);
+        if (P >= 4 && ti.twin && ctx->info.symmetric && env_i64("GPM_NO_FUSE3", 0) == 0) {
+            const int Z = P - 3;
+            const LevelPlan &LZ = pv.lv[Z];
+            unsigned zset = 1u << LZ.src_level, aset = 1u << A.src_level;
+            for (int j = 0; j < LZ.n_cons; ++j) zset |= 1u << LZ.cons_level[j];
+            for (int j = 0; j < A.n_cons; ++j) aset |= 1u << A.cons_level[j];
+            const bool related = lt[Z][L] || lt[L][Z];
+            if ((zset & ~aset) == 0 && (aset >> Z & 1u) && !related) {
+                for (int t = 0; t < Z; ++t) {
+                    if (zset >> t & 1u) t3.zl[t3.n_zl++] = (int8_t)t;
+                    else if (aset >> t & 1u) t3.xl[t3.n_xl++] = (int8_t)t;
+                }
+                t3.enabled = 1;
+            }
+        }
         // leaf levels: adjacency to the source is the only requirement besides the label
         const bool closed_ok = ctx->info.simple && ctx->info.symmetric && env_i64("GPM_NO_LEAF", 0) == 0;
         auto leaf = [&](const LevelPlan &X) {
@@ -1188,6 +1213,47 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
     const int32_t *rows = d.F[k - 1];
     progress_tick(d.dev, d.chunks, ctx->chunks.size(), k, nrows);
 
+    if (a.count_only && ctx->use_tail && k == P - 3 && ctx->t3.enabled && !d.no_fuse3) {
+        if (!d.over_rows) HIP_TRY(hipMalloc(&d.over_rows, 2 * (size_t)d.cap_rows * sizeof(int64_t)));
+        int64_t *over1 = d.over_rows, *over2 = d.over_rows + d.cap_rows;
+        HIP_TRY(hipMemsetAsync(d.ctr + CTR_OVER, 0, 2 * sizeof(unsigned long long), s));
+        // 16 lanes and sets of up to 64 per partial match; what does not fit goes to whole waves with
+        // sets of up to 1024; what still does not fit goes level by level
+        unsigned blocks = (unsigned)std::min<int64_t>((nrows * 16 + 255) / 256, 1 << 16);
+        int rc = timed_begin(d, GPM_KIND_TAIL, nrows);
+        if (rc) return rc;
+        k_tail3<16, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, over1,
+                                              d.ctr + CTR_OVER, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_TAIL_BYTES);
+        HIP_TRY(hipGetLastError());
+        if ((rc = timed_end(d))) return rc;
+        uint64_t n_over = 0;
+        if ((rc = read_ctr(d, CTR_OVER, &n_over))) return rc;
+        if (n_over == 0) return GPM_OK;
+        if (env_i64("GPM_FUSE3_WAVE", 1) == 0) {  // tests: straight to the level-by-level path
+            over2 = over1;
+        } else {
+        blocks = (unsigned)std::min<uint64_t>((n_over * 64 + 255) / 256, 1 << 16);
+        if ((rc = timed_begin(d, GPM_KIND_TAIL, (int64_t)n_over))) return rc;
+        k_tail3<64, 1024><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, over1, (int64_t)n_over, over2,
+                                                d.ctr + CTR_OVER + 1, d.ctr + CTR_TAIL_MATCHES,
+                                                d.ctr + CTR_TAIL_BYTES);
+        HIP_TRY(hipGetLastError());
+        if ((rc = timed_end(d))) return rc;
+        if ((rc = read_ctr(d, CTR_OVER + 1, &n_over))) return rc;
+        if (n_over == 0) return GPM_OK;
+        }
+        // the partial matches whose sets did not fit a lane group: compact them to the front of this
+        // frontier (through the next level's arena) and expand them level by level
+        k_gather_rows<<<grid_for((int64_t)n_over * k), 256, 0, s>>>(rows, over2, (int64_t)n_over, k, d.F[k]);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(d.F[k - 1], d.F[k], (size_t)n_over * (size_t)k * sizeof(int32_t),
+                               hipMemcpyDeviceToDevice, s));
+        d.rows_in[k - 1] -= n_over;  // counted again by the call below
+        d.no_fuse3 = true;
+        rc = expand(a, d, k, (int64_t)n_over);
+        d.no_fuse3 = false;
+        return rc;
+    }
     if (a.count_only && ctx->use_tail && k == P - 2 && ctx->ti.leaf_pair) {
         int rc = timed_begin(d, GPM_KIND_TAIL, nrows);
         if (rc) return rc;

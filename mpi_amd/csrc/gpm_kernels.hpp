@@ -498,6 +498,123 @@ __global__ __launch_bounds__(256) void k_tail_twin(GraphView g, PlanView pl, Tai
     }
 }
 
+// Three fused levels: level Z = P-3 followed by twin last levels whose lists are
+// Z's lists, the list of the Z vertex itself and possibly lists of further
+// earlier vertices (K6 minus a perfect matching: z, then two twins adjacent to
+// z and to everything z is adjacent to).  For one partial match of length P-3
+// the common part T of Z's lists is walked once; its members that pass Z's
+// bounds and filters are the candidates z, its members that pass the twins'
+// bounds, filters and further lists are the set B the twins draw from whatever
+// z is, and every z then only needs |B ^ N(z)|.  This replaces one extension
+// level and its frontier, and the recomputation of T for every z.  G lanes per
+// partial match and sets of at most CAP vertices; partial matches with larger
+// sets are handed back (`over`): first to a launch with whole waves and larger
+// sets, then to the level-by-level path.  `sel` (optional) lists the partial
+// matches to take.
+struct Tail3Info {
+    int8_t enabled;
+    int8_t n_zl, zl[GPM_MAXC + 1];  // levels whose lists level Z intersects
+    int8_t n_xl, xl[GPM_MAXC + 1];  // further levels whose lists the twins need
+};
+
+__device__ __forceinline__ bool t3_level_ok(const GraphView &g, const LevelPlan &lv, const int32_t *m, int32_t c) {
+    for (int j = 0; j < lv.n_lower; ++j)
+        if (c <= m[lv.lower_level[j]]) return false;
+    for (int j = 0; j < lv.n_upper; ++j)
+        if (c >= m[lv.upper_level[j]]) return false;
+    return vertex_ok(g, lv, c);
+}
+
+template <int G, int CAP>
+__global__ __launch_bounds__(256) void k_tail3(GraphView g, PlanView pl, TailInfo ti, Tail3Info t3, const int32_t *rows,
+                                               const int64_t *sel, int64_t nrows, int64_t *over,
+                                               unsigned long long *n_over, unsigned long long *n_matches,
+                                               unsigned long long *alg_bytes) {
+    __shared__ int32_t s_z[256 / G][CAP], s_b[256 / G][CAP];
+    const int lane = lane_id(), sub = lane & (G - 1), shift = lane & ~(G - 1), grp = threadIdx.x / G;
+    const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1);
+    const int L0 = pl.P - 3;
+    const LevelPlan &lz = pl.lv[L0], &la = pl.lv[L0 + 1];
+    const int64_t groups = (int64_t)gridDim.x * (256 / G);
+    int32_t *zs = s_z[grp], *bs = s_b[grp];
+    uint64_t cnt = 0, bytes = 0;
+    for (int64_t ri = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G; ri < nrows; ri += groups) {
+        const int64_t r = sel ? sel[ri] : ri;
+        const int32_t *m = rows + r * L0;
+        // walk the shortest of Z's lists, whole (bounds are tested per element: the twins' differ from Z's)
+        int wl = 0;
+        int64_t wb = g.off[0][m[t3.zl[0]]], we = g.off[0][m[t3.zl[0]] + 1];
+        for (int j = 1; j < t3.n_zl; ++j) {
+            const int64_t cb = g.off[0][m[t3.zl[j]]], ce = g.off[0][m[t3.zl[j]] + 1];
+            if (ce - cb < we - wb) {
+                wb = cb;
+                we = ce;
+                wl = j;
+            }
+        }
+        int nz = 0, nb = 0;
+        for (int64_t i0 = wb; i0 < we && nz <= CAP && nb <= CAP; i0 += G) {
+            const int64_t i = i0 + sub;
+            bool ok = i < we;
+            int32_t c = 0;
+            if (ok) {
+                c = g.adj[0][i];
+                for (int t = 0; t < L0; ++t) ok = ok && m[t] != c;
+                for (int j = 0; j < t3.n_zl && ok; ++j)
+                    if (j != wl) ok = in_list(g, 0, PART_FULL, m[t3.zl[j]], c);
+            }
+            const bool zok = ok && t3_level_ok(g, lz, m, c);
+            bool bok = ok && t3_level_ok(g, la, m, c);
+            for (int j = 0; j < t3.n_xl && bok; ++j) bok = in_list(g, 0, PART_FULL, m[t3.xl[j]], c);
+            const unsigned long long mz = (__ballot(zok) >> shift) & gmask, mb = (__ballot(bok) >> shift) & gmask;
+            const unsigned long long below = (1ull << sub) - 1;
+            if (zok) {
+                const int p = nz + __popcll(mz & below);
+                if (p < CAP) zs[p] = c;
+            }
+            if (bok) {
+                const int p = nb + __popcll(mb & below);
+                if (p < CAP) bs[p] = c;
+            }
+            nz += __popcll(mz);
+            nb += __popcll(mb);
+        }
+        wave_lds_sync();
+        if (nz > CAP || nb > CAP) {  // too large for the group: handed back
+            if (sub == 0) over[atomicAdd(n_over, 1ull)] = r;
+            wave_lds_sync();
+            continue;
+        }
+        if (sub == 0) bytes += level_bytes(g, lz, m, L0);
+        for (int zi = sub; zi < nz; zi += G) {
+            const int32_t z = zs[zi];
+            uint32_t sc = 0;
+            for (int bi = 0; bi < nb; ++bi) {
+                const int32_t b = bs[bi];
+                sc += b != z && in_list(g, 0, PART_FULL, z, b);
+            }
+            const uint64_t s_all = sc;
+            const uint64_t pairs = s_all * (s_all - (s_all ? 1 : 0));
+            cnt += (ti.b_lower_is_a || ti.b_upper_is_a) ? pairs / 2 : pairs;
+            bytes += (s_all + 1) * level_bytes(g, la, m, L0 + 1, L0, z) + 4ull * s_all;
+        }
+        wave_lds_sync();
+    }
+    cnt = wave_sum_u64(cnt);
+    bytes = wave_sum_u64(bytes);
+    if (lane == 0) {
+        if (cnt) atomicAdd(n_matches, (unsigned long long)cnt);
+        if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
+    }
+}
+
+// Rows `idx[0..n)` of a frontier of k ids per row, gathered into `out`.
+__global__ void k_gather_rows(const int32_t *rows, const int64_t *idx, int64_t n, int k, int32_t *out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * k) return;
+    out[t] = rows[idx[t / k] * k + t % k];
+}
+
 // Last two levels when both are leaf levels hanging off earlier vertices: one
 // thread per partial match, candidates counted in closed form: |A| * |B| minus
 // the pairs that would bind the same vertex twice.

@@ -140,6 +140,7 @@ VARIANTS = [
     {"symbreak": True, "env": {"GPM_NO_TWIN": "1", "GPM_NO_CYCLE4": "1"}},
     {"symbreak": True, "env": {"GPM_NO_LABEL_SEGMENTS": "1"}},
     {"symbreak": True, "env": {"GPM_PLAN_ORDER": "reference"}},
+    {"symbreak": True, "env": {"GPM_NO_FUSE3": "1"}},
     {"symbreak": True, "env": {"GPM_NO_INDEP": "1"}},
     {"symbreak": False, "env": {"GPM_NO_INDEP": "1"}},
 ]
@@ -319,6 +320,26 @@ def test_directed_acyclic_clique_equals_the_undirected_count():
     m.set_pattern(gen.PATTERNS["tri_dir"])
     assert m.findMatches(count_only=True) == 0  # no directed cycle in an acyclic orientation
     m.close()
+
+
+@pytest.mark.parametrize("pname", ["k6_minus_pm", "k6_minus_e"])
+def test_three_fused_levels_equal_the_level_by_level_path(pname, monkeypatch):
+    """Patterns that end in twins hanging off the level before them: the three-level kernel (incl. the
+    partial matches it hands back because their sets exceed a lane group) gives the count and the
+    merge-model bytes of the level-by-level path."""
+    n, s, d = util.build_graph({"graph": "rmat", "scale": 11, "ef": 8, "abcd": (0.7, 0.1, 0.1, 0.1), "seed": 1})
+    got = []
+    for off, wave in (("1", "1"), ("0", "1"), ("0", "0")):  # off; lane groups then whole waves; lane groups then level by level
+        monkeypatch.setenv("GPM_NO_FUSE3", off)
+        monkeypatch.setenv("GPM_FUSE3_WAVE", wave)
+        m = binding.Matcher(1)
+        upload(m, n, s, d)
+        m.set_pattern(gen.PATTERNS[pname])
+        c = m.findMatches(count_only=True)
+        st = m.stats()
+        got.append((c, st.alg_bytes))
+        m.close()
+    assert got[0] == got[1] == got[2] and got[0][0] > 0
 
 
 def test_clique_kernel_equals_generic_path(monkeypatch):
