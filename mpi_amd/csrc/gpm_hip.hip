@@ -171,6 +171,7 @@ struct gpm_ctx {
     PlanView pv{};
     TailInfo ti{};
     Tail3Info t3{};
+    LeafSuffix ls{};
     bool use_tail = true;
     int clique_k = 0;  // K when the plan is a K-clique under a total ordering, else 0
     bool use_clique = true;
@@ -898,6 +899,72 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
         ti.leaf_pair = closed_ok && leaf(A) && leaf(B) && B.src_level != L && (same_set || disjoint);
         ti.pair_same_set = same_set;
     }
+    // leaf suffix: every level from S on is a leaf (see k_leaf_suffix)
+    LeafSuffix &ls = ctx->ls;
+    memset(&ls, 0, sizeof ls);
+    if (P >= 3 && ctx->info.simple && ctx->info.symmetric && env_i64("GPM_NO_LEAF", 0) == 0 &&
+        env_i64("GPM_NO_LEAF_SUFFIX", 0) == 0) {
+        auto leaf = [&](const LevelPlan &X) {
+            return X.n_cons == 0 && X.n_upper == 0 && X.min_out <= 1 && X.min_in <= 1 &&
+                   (X.label < 0 || ctx->devs[0].gv.labcnt != nullptr);
+        };
+        int S = P;
+        while (S - 1 >= 1 && leaf(pv.lv[S - 1])) --S;
+        bool ok = P - S >= 2;
+        for (int k = S; k < P && ok; ++k) ok = pv.lv[k].src_level < S;  // leaves hang off inner vertices
+        // all leaves labelled or none
+        for (int k = S; k < P && ok; ++k) ok = (pv.lv[k].label < 0) == (pv.lv[S].label < 0);
+        for (int k = S; k < P && ok; ++k) {
+            const LevelPlan &lv = pv.lv[k];
+            int c = -1;
+            for (int i = 0; i < ls.n_cls; ++i)
+                if (ls.cls[i].label == lv.label) c = i;
+            if (c < 0) {
+                if (ls.n_cls == 4) { ok = false; break; }
+                c = ls.n_cls++;
+                ls.cls[c].label = lv.label;
+            }
+            LeafClass &lc = ls.cls[c];
+            int gi = -1;
+            for (int i = 0; i < lc.n_grp; ++i)
+                if (lc.src[i] == lv.src_level) gi = i;
+            if (gi < 0) {
+                if (lc.n_grp == 2) { ok = false; break; }
+                gi = lc.n_grp++;
+                lc.src[gi] = lv.src_level;
+                lc.level0[gi] = (int8_t)k;
+            }
+            lc.cnt[gi]++;
+            ls.cls_of[k] = (int8_t)c;
+            ls.grp_of[k] = (int8_t)gi;
+        }
+        // ordering bounds: none, or a chain through the leaves of one group; nothing else
+        for (int c = 0; c < ls.n_cls && ok; ++c)
+            for (int gi = 0; gi < ls.cls[c].n_grp && ok; ++gi) {
+                int prev = -1, chained = 0, members = 0;
+                for (int k = S; k < P && ok; ++k) {
+                    if (ls.cls_of[k] != c || ls.grp_of[k] != gi) continue;
+                    const LevelPlan &lv = pv.lv[k];
+                    members++;
+                    if (lv.n_lower == 0) {
+                        ok = chained == 0;  // either every later member is chained or none is
+                    } else {
+                        ok = lv.n_lower == 1 && lv.lower_level[0] == prev;
+                        chained++;
+                    }
+                    prev = k;
+                }
+                ok = ok && (chained == 0 || chained == members - 1);
+                ls.cls[c].ordered[gi] = chained > 0;
+            }
+        // bounds from leaves towards other levels would show up as lower bounds of those levels
+        for (int k = 1; k < P && ok; ++k)
+            for (int j = 0; j < pv.lv[k].n_lower && ok; ++j)
+                if (pv.lv[k].lower_level[j] >= S) ok = k >= S && ls.cls_of[k] == ls.cls_of[pv.lv[k].lower_level[j]] &&
+                                                       ls.grp_of[k] == ls.grp_of[pv.lv[k].lower_level[j]];
+        ls.enabled = ok;
+        ls.S = (int8_t)S;
+    }
     // K-clique under a total order: every level's operand lists are the lists of
     // all earlier levels, each vertex is bounded below by its predecessor, and
     // nothing but adjacency filters the candidates.
@@ -1213,6 +1280,15 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
     const int32_t *rows = d.F[k - 1];
     progress_tick(d.dev, d.chunks, ctx->chunks.size(), k, nrows);
 
+    if (a.count_only && ctx->use_tail && ctx->ls.enabled && k == ctx->ls.S) {
+        const unsigned blocks = (unsigned)std::min<int64_t>((nrows + TAIL_WAVES - 1) / TAIL_WAVES, 16384);
+        int rc = timed_begin(d, GPM_KIND_TAIL, nrows);
+        if (rc) return rc;
+        k_leaf_suffix<<<blocks, TAIL_WAVES * GPM_WAVE, 0, s>>>(d.gv, ctx->pv, ctx->ls, rows, nrows,
+                                                              d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_TAIL_BYTES);
+        HIP_TRY(hipGetLastError());
+        return timed_end(d);
+    }
     if (a.count_only && ctx->use_tail && k == P - 3 && ctx->t3.enabled && !d.no_fuse3) {
         if (!d.over_rows) HIP_TRY(hipMalloc(&d.over_rows, 2 * (size_t)d.cap_rows * sizeof(int64_t)));
         int64_t *over1 = d.over_rows, *over2 = d.over_rows + d.cap_rows;

@@ -673,6 +673,138 @@ __global__ void k_label_segments(GraphView g, const uint32_t *labcnt, uint32_t *
     seg[g.nlab] = run;
 }
 
+// ---------------------------------------------------------------------------
+// Leaf suffix: every level from S on is a leaf
+// ---------------------------------------------------------------------------
+//
+// When the last q >= 2 levels are all leaves (one neighbour in the pattern, no
+// other requirement than the label), the number of ways to bind them for one
+// partial match m of the S inner vertices has a closed form.  Leaves can only
+// clash when they carry the same label, so they are grouped by label and,
+// inside a label, by the inner vertex they hang off; at most two such groups
+// per label are handled (A = free neighbours of s1 with the label, a leaves;
+// B = those of s2, b leaves; t = |A ^ B|):
+//     W(a, b) = sum_j (-1)^j C(a,j) C(b,j) j! t^(j) (|A|-j)^(a-j) (|B|-j)^(b-j)
+// (x^(k) = falling factorial; the sum runs over the numbers j of leaf pairs
+// forced onto a common vertex), divided by a! or b! when ordering bounds make
+// the leaves of a group interchangeable.  Only t needs a list intersection,
+// one per partial match of the inner vertices instead of one partial match per
+// leaf binding.  Counts are taken modulo 2^64 like every other count here.
+// Algorithmic bytes: the row, the degree lookups and both operands of the
+// intersection -- what the closed form needs, not what enumerating would read.
+
+struct LeafClass {
+    int32_t label;                 // -1: unlabelled
+    int8_t n_grp;                  // 1 or 2 groups
+    int8_t src[2], cnt[2], ordered[2], level0[2];  // inner level, leaves, bounds make them a chain, first leaf level
+};
+struct LeafSuffix {
+    int8_t enabled, S, n_cls;
+    LeafClass cls[4];
+    int8_t cls_of[GPM_MAXP], grp_of[GPM_MAXP];  // class and group of every leaf level
+};
+
+__device__ __forceinline__ __int128 falling128(long long x, int k) {
+    __int128 r = 1;
+    for (int i = 0; i < k; ++i) r *= (x - i > 0 ? x - i : 0);
+    return r;
+}
+
+// Ways to bind a leaves off s1 and b leaves off s2 (see above), ordered tuples.
+__device__ __forceinline__ __int128 leaf_ways(long long A, long long B, long long t, int a, int b) {
+    if (b == 0) return falling128(A, a);
+    if (a == 0) return falling128(B, b);
+    __int128 sum = 0;
+    long long binom_a = 1, binom_b = 1, jfact = 1;
+    for (int j = 0; j <= a && j <= b; ++j) {
+        if (j > 0) {
+            binom_a = binom_a * (a - j + 1) / j;
+            binom_b = binom_b * (b - j + 1) / j;
+            jfact *= j;
+        }
+        __int128 term = (__int128)(binom_a * binom_b * jfact) * falling128(t, j) * falling128(A - j, a - j) *
+                        falling128(B - j, b - j);
+        sum += (j & 1) ? -term : term;
+    }
+    return sum;
+}
+
+__device__ __forceinline__ long long small_factorial(int k) {
+    long long r = 1;
+    for (int i = 2; i <= k; ++i) r *= i;
+    return r;
+}
+
+// One wave per partial match of the S inner vertices.
+__global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_leaf_suffix(GraphView g, PlanView pl, LeafSuffix ls,
+                                                                      const int32_t *rows, int64_t nrows,
+                                                                      unsigned long long *n_matches,
+                                                                      unsigned long long *alg_bytes) {
+    const int wave = threadIdx.x / GPM_WAVE, lane = lane_id();
+    const int S = ls.S;
+    uint64_t cnt = 0, bytes = 0;
+    for (int64_t r = (int64_t)blockIdx.x * TAIL_WAVES + wave; r < nrows; r += (int64_t)gridDim.x * TAIL_WAVES) {
+        const int32_t *m = rows + r * S;
+        long long A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0}, T[4] = {0, 0, 0, 0};
+        for (int c = 0; c < ls.n_cls; ++c) {
+            const LeafClass &lc = ls.cls[c];
+            const int32_t s1 = m[lc.src[0]];
+            A[c] = leaf_count(g, pl.lv[lc.level0[0]], m, S, s1);
+            if (lane == 0) bytes += 20ull * (uint64_t)lc.n_grp;  // two offsets and a label count per group
+            if (lc.n_grp < 2) continue;
+            const int32_t s2 = m[lc.src[1]];
+            B[c] = leaf_count(g, pl.lv[lc.level0[1]], m, S, s2);
+            // t: common free neighbours with the label -- walk the shorter list (its label segment when
+            // there is one: ids ascend inside it), look each entry up in the other
+            int64_t b1, e1, b2, e2;
+            const int32_t *arr = g.adj[0];
+            if (lc.label >= 0 && g.adjL) {
+                arr = g.adjL;
+                const uint32_t *g1 = g.labseg + (size_t)s1 * (size_t)(g.nlab + 1) + (size_t)lc.label;
+                const uint32_t *g2 = g.labseg + (size_t)s2 * (size_t)(g.nlab + 1) + (size_t)lc.label;
+                b1 = g.off[0][s1] + g1[0], e1 = g.off[0][s1] + g1[1];
+                b2 = g.off[0][s2] + g2[0], e2 = g.off[0][s2] + g2[1];
+            } else {
+                b1 = g.off[0][s1], e1 = g.off[0][s1 + 1];
+                b2 = g.off[0][s2], e2 = g.off[0][s2 + 1];
+            }
+            if (e2 - b2 < e1 - b1) {
+                int64_t x = b1; b1 = b2; b2 = x;
+                x = e1; e1 = e2; e2 = x;
+            }
+            if (lane == 0) bytes += 4ull * (uint64_t)((e1 - b1) + (e2 - b2));  // both operands, merge model
+            uint32_t common = 0;
+            for (int64_t i = b1 + lane; i < e1; i += GPM_WAVE) {
+                const int32_t v = arr[i];
+                if (lc.label >= 0 && !g.adjL && g.label[v] != (uint8_t)lc.label) continue;
+                bool in = contains_g(arr, b2, e2, v);
+                for (int t = 0; t < S && in; ++t) in = m[t] != v;  // bound vertices are not free
+                common += in;
+            }
+            T[c] = (long long)wave_sum_u64(common);
+            T[c] = __shfl(T[c], 0, GPM_WAVE);
+        }
+        if (lane != 0) continue;
+        bytes += 4ull * (uint64_t)S;
+        unsigned __int128 ways = 1;
+        for (int c = 0; c < ls.n_cls; ++c) {
+            const LeafClass &lc = ls.cls[c];
+            const int a = lc.cnt[0], b = lc.n_grp > 1 ? lc.cnt[1] : 0;
+            __int128 w = leaf_ways(A[c], B[c], T[c], a, b);
+            if (lc.ordered[0]) w /= small_factorial(a);
+            if (lc.n_grp > 1 && lc.ordered[1]) w /= small_factorial(b);
+            ways *= (unsigned __int128)(w > 0 ? w : 0);
+        }
+        cnt += (uint64_t)ways;
+    }
+    cnt = wave_sum_u64(cnt);
+    bytes = wave_sum_u64(bytes);
+    if (lane == 0) {
+        if (cnt) atomicAdd(n_matches, (unsigned long long)cnt);
+        if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
+    }
+}
+
 // Neighbours per label of every vertex (thread per vertex).
 __global__ void k_label_counts(GraphView g, uint32_t *labcnt) {
     int32_t v = blockIdx.x * blockDim.x + threadIdx.x;

@@ -143,6 +143,7 @@ VARIANTS = [
     {"symbreak": True, "env": {"GPM_NO_FUSE3": "1"}},
     {"symbreak": True, "env": {"GPM_NO_INDEP": "1"}},
     {"symbreak": False, "env": {"GPM_NO_INDEP": "1"}},
+    {"symbreak": True, "env": {"GPM_NO_LEAF_SUFFIX": "1"}},
 ]
 VAR_SPECS = [g for g in GOLDEN if g["name"] in (
     "rand9_sym_clique4", "rand9_sym_cycle4", "rand9_dir_tree5_dir", "rand40_dir_rev4", "rand40_dir_k4_dag",
@@ -417,6 +418,64 @@ def test_leaf_levels_counted_in_closed_form(pname, symbreak, labelled, plan_orde
         got.append(m.findMatches(count_only=True))
         m.close()
     assert got == [want, want]
+
+
+def _und(pairs):
+    return sorted({(a, b) for a, b in pairs} | {(b, a) for a, b in pairs})
+
+
+LEAFY = {
+    "star5": (5, _und([(1, 2), (1, 3), (1, 4), (1, 5)])),
+    "star6": (6, _und([(1, 2), (1, 3), (1, 4), (1, 5), (1, 6)])),
+    "dstar6": (6, _und([(1, 2), (1, 3), (1, 4), (2, 5), (2, 6)])),
+    "dstar7": (7, _und([(1, 2), (1, 3), (1, 4), (1, 5), (2, 6), (2, 7)])),
+    "broom5": (5, _und([(1, 2), (2, 3), (3, 4), (3, 5)])),
+    "caterpillar6": (6, _und([(1, 2), (2, 3), (1, 4), (2, 5), (3, 6)])),
+    "tri_leaves6": (6, _und([(1, 2), (2, 3), (1, 3), (1, 4), (1, 5), (2, 6)])),
+    "tri_leaves7": (7, _und([(1, 2), (2, 3), (1, 3), (1, 4), (1, 5), (2, 6), (2, 7)])),
+    "cyc_leaves6": (6, _und([(1, 2), (2, 3), (3, 4), (4, 1), (1, 5), (3, 6)])),
+}
+LEAFY_LABELS = {
+    "star5": [[0, 1, 1, 1, 1], [0, 1, 1, 2, 2], [1, 0, 1, 2, 0]],
+    "star6": [[0, 1, 1, 1, 2, 2]],
+    "dstar6": [[0, 0, 1, 1, 1, 1], [0, 1, 2, 2, 2, 0], [1, 1, 0, 2, 0, 2]],
+    "dstar7": [[0, 0, 1, 1, 1, 1, 1], [0, 1, 2, 2, 0, 2, 0]],
+    "broom5": [[0, 1, 2, 0, 0]],
+    "caterpillar6": [[0, 1, 2, 0, 0, 0], [0, 1, 2, 0, 1, 2]],
+    "tri_leaves6": [[0, 0, 0, 1, 1, 1], [0, 1, 2, 2, 1, 2]],
+    "tri_leaves7": [[0, 0, 1, 2, 2, 2, 2]],
+    "cyc_leaves6": [[0, 1, 0, 1, 2, 2]],
+}
+
+
+@pytest.mark.parametrize("pname", sorted(LEAFY))
+def test_leaf_suffix_closed_form(pname, monkeypatch):
+    """Patterns whose last levels are all leaves (stars, double stars, brooms, a triangle or a
+    4-cycle with pendant vertices), unlabelled and with several labellings, symmetry breaking on
+    and off: the count with the whole leaf suffix in closed form equals the count with that
+    closed form switched off, and on a small graph both equal the oracle's enumeration."""
+    pat = LEAFY[pname]
+    P = pat[0]
+    small = util.build_graph({"graph": "plaw", "n": 96, "avg_deg": 4, "seed": 5})
+    big = util.build_graph({"graph": "rmat", "scale": 9, "ef": 6, "seed": 4})
+    for gi, (n, s, d) in enumerate((small, big)):
+        for pl in [None] + LEAFY_LABELS[pname]:
+            dl = None if pl is None else gen.vertex_labels(n, 3, seed=11).numpy().astype(np.int32)
+            want = None
+            if gi == 0:
+                want, _, _ = util.oracle_matches(n, s, d, pat, data_labels=dl, pattern_labels=pl, want_rows=False)
+            for symbreak in (True, False):
+                got = []
+                for off in ("0", "1"):
+                    monkeypatch.setenv("GPM_NO_LEAF_SUFFIX", off)
+                    m = binding.Matcher(1)
+                    upload(m, n, s, d, labels=dl)
+                    m.set_pattern(pat, labels=pl, symbreak=symbreak)
+                    got.append(m.findMatches(count_only=True))
+                    m.close()
+                assert got[0] == got[1], (pname, pl, symbreak, gi, got)
+                if want is not None:
+                    assert got[0] == want, (pname, pl, symbreak, got, want)
 
 
 LABELLED = [("triangle", [0, 0, 1]), ("triangle", [2, 2, 2]), ("clique4", [0, 0, 1, 1]), ("clique4", [1, 1, 1, 1]),
