@@ -144,6 +144,7 @@ struct DevState {
     uint32_t *cyc_dense = nullptr;
     int64_t cyc_stride = 0;
     int cyc_blocks = 0;
+    int cyc_batch = 1;     // heavy roots per launch
     unsigned long long *cyc_queue = nullptr;
     std::vector<EventPair> events;
     size_t events_used = 0;
@@ -425,7 +426,7 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->use_tail = env_i64("GPM_NO_TAIL", 0) == 0;
     ctx->use_clique = env_i64("GPM_NO_CLIQUE", 0) == 0;
     ctx->use_cycle4 = env_i64("GPM_NO_CYCLE4", 0) == 0;
-    ctx->cyc_heavy_thr = std::max<int64_t>(1, env_i64("GPM_CYCLE4_HEAVY", (int64_t)1 << 21));
+    ctx->cyc_heavy_thr = std::max<int64_t>(1, env_i64("GPM_CYCLE4_HEAVY", (int64_t)1 << 16));
     // GPM_NO_RCCL=1: per-GPU counts are summed on the host only (also lets two workers share one GPU in tests)
     if ((ngpus > 1 && env_i64("GPM_NO_RCCL", 0) == 0) || env_i64("GPM_FORCE_RCCL", 0)) {
         if (!rccl().ok()) {
@@ -1614,8 +1615,12 @@ static int ensure_cycle4(gpm_ctx *ctx, DevState &d) {
     const int64_t n = ctx->info.n, m = d.m[0];
     d.cyc_stride = (n + 63) / 64 * 64 + 64;
     const int64_t budget = env_i64("GPM_CYCLE4_MEM_GB", 32) << 30;
-    d.cyc_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(64, budget / (4 * d.cyc_stride) - CYC_HEAVY_SLABS));
-    const size_t dense_bytes = ((size_t)d.cyc_blocks + CYC_HEAVY_SLABS) * (size_t)d.cyc_stride * sizeof(uint32_t);
+    // half of the budget for the heavy roots' arrays (CYC_HEAVY_GROUPS groups of cyc_batch), the rest for
+    // the light workgroups' arrays
+    const int64_t arrays = std::max<int64_t>(8, budget / (4 * d.cyc_stride));
+    d.cyc_batch = (int)std::min<int64_t>(CYC_BATCH, std::max<int64_t>(1, arrays / 2 / CYC_HEAVY_GROUPS));
+    d.cyc_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(64, arrays - CYC_HEAVY_GROUPS * d.cyc_batch));
+    const size_t dense_bytes = ((size_t)d.cyc_blocks + CYC_HEAVY_GROUPS * d.cyc_batch) * (size_t)d.cyc_stride * sizeof(uint32_t);
     HIP_TRY(hipMalloc(&d.cyc_cost, ((size_t)n + 1) * sizeof(int64_t)));
     HIP_TRY(hipMalloc(&d.cyc_wp, ((size_t)m + 2) * sizeof(int64_t)));
     HIP_TRY(hipMalloc(&d.cyc_dense, dense_bytes));
@@ -1636,6 +1641,8 @@ static int ensure_cycle4(gpm_ctx *ctx, DevState &d) {
         HIP_TRY(hipFree(tmp));
         HIP_TRY(hipFree(len));
     }
+    HIP_TRY(hipFuncSetAttribute((const void *)k_cycle4_heavy, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)CYC_HEAVY_LDS_BYTES));
     if (n > 0) k_cycle4_cost<<<grid_for(n), 256, 0, s>>>(d.gv, d.cyc_wp, n, d.cyc_cost);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -1770,6 +1777,7 @@ static int device_search(const SearchArgs &a, DevState &d) {
         HIP_TRY(hipStreamSynchronize(s));
     }
     uint64_t seq = 0, cyc_heavy_seq = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
     while (!ctx->stop) {
         const uint64_t c = claim_chunk(ctx);
         if (c >= ctx->chunks.size()) break;
@@ -1795,21 +1803,31 @@ static int device_search(const SearchArgs &a, DevState &d) {
             if ((rc = timed_end(d, ls))) return rc;
             seq++;
             const auto &hv = ctx->cyc_heavy_roots;
-            for (size_t h = (size_t)(std::lower_bound(hv.begin(), hv.end(), lo) - hv.begin()); h < hv.size() && hv[h] < hi;
-                 ++h) {
-                const int32_t v1 = (int32_t)(ctx->info.n - 1 - hv[h]);
-                const int slab = (int)(cyc_heavy_seq++ % CYC_HEAVY_SLABS);
-                hipStream_t hs = slab == 0 ? s : d.slots[slab].stream;
-                uint32_t *cnt = d.cyc_dense + (size_t)slab * (size_t)d.cyc_stride;
-                const int64_t nblk = (ctx->cyc_heavy_paths[h] + CYC_BLOCK - 1) / CYC_BLOCK;
-                const unsigned grid = (unsigned)std::min<int64_t>(1024, (nblk + 3) / 4);
-                if ((rc = timed_begin(d, GPM_KIND_CYCLE4, 1, hs))) return rc;
-                k_cycle4_heavy<<<grid, 256, 0, hs>>>(d.gv, d.cyc_wp, v1, cnt, d.ctr + CTR_TAIL_MATCHES,
-                                                     d.ctr + CTR_CYC_BYTES);
+            // heavy roots of the chunk, CYC_BATCH per launch; the light launches keep a stream (and with it
+            // a hardware queue) of their own, so the batches alternate between the other three
+            const int64_t hblock = std::max<int64_t>(256, env_i64("GPM_CYC_HEAVY_BLOCK", 2048)) / 256 * 256;
+            const int64_t span = std::max<int64_t>(1, env_i64("GPM_CYC_SPAN", (int64_t)1 << 18) / hblock) * hblock;
+            size_t h = (size_t)(std::lower_bound(hv.begin(), hv.end(), lo) - hv.begin());
+            while (h < hv.size() && hv[h] < hi) {
+                CycBatch b{};
+                int64_t max_v1 = 0;
+                while (b.n < d.cyc_batch && h < hv.size() && hv[h] < hi) {
+                    b.v1[b.n] = (int32_t)(ctx->info.n - 1 - hv[h]);
+                    max_v1 = std::max<int64_t>(max_v1, b.v1[b.n]);
+                    b.wg0[b.n + 1] = b.wg0[b.n] + (int32_t)((ctx->cyc_heavy_paths[h] + span - 1) / span);
+                    b.n++;
+                    h++;
+                }
+                const int group = (int)(cyc_heavy_seq++ % CYC_HEAVY_GROUPS);
+                hipStream_t hs = d.slots[group + 1].stream;
+                uint32_t *dense = d.cyc_dense + ((size_t)d.cyc_blocks + (size_t)group * d.cyc_batch) * (size_t)d.cyc_stride;
+                if ((rc = timed_begin(d, GPM_KIND_CYCLE4, b.n, hs))) return rc;
+                k_cycle4_heavy<<<(unsigned)b.wg0[b.n], CYC_HEAVY_WAVES * GPM_WAVE, CYC_HEAVY_LDS_BYTES, hs>>>(
+                    d.gv, d.cyc_wp, b, dense, d.cyc_stride, span, hblock, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_CYC_BYTES);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)v1 * sizeof(uint32_t), hs));
+                HIP_TRY(hipMemsetAsync(dense, 0, ((size_t)(b.n - 1) * (size_t)d.cyc_stride + (size_t)max_v1) * sizeof(uint32_t), hs));
                 if ((rc = timed_end(d, hs))) return rc;
-                progress_tick(d.dev, d.chunks, ctx->chunks.size(), 0, hv[h]);
+                progress_tick(d.dev, d.chunks, ctx->chunks.size(), 0, (int64_t)h);
                 if (d.events_used > 4096) {
                     for (auto &x : d.slots) HIP_TRY(hipStreamSynchronize(x.stream));
                     HIP_TRY(hipStreamSynchronize(s));
@@ -1869,6 +1887,9 @@ static int device_search(const SearchArgs &a, DevState &d) {
             if (rc) return rc;
         }
     }
+    if (getenv("GPM_TRACE"))
+        fprintf(stderr, "gpm trace: all chunks enqueued %.3f ms after the search began\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     if (cyc)
         for (auto &x : d.slots) HIP_TRY(hipStreamSynchronize(x.stream));
     if (clique) {

@@ -1511,19 +1511,48 @@ __global__ void k_cycle4_cost(GraphView g, const int64_t *wp, int64_t nroots, in
 // One wave's pass over blocks blk0, blk0 + bstep, ... of the two-paths of root
 // v1.  RESET = false: count, returns the sum of the old counter values;
 // RESET = true: store zeros.  s_pre / s_beg are this wave's 64-entry LDS arrays.
-template <bool RESET>
+//
+// Hot counters.  A two-path of a heavy root lands, on average, on a counter
+// that more than a hundred others land on as well (hub to hub pairs), and
+// atomics on one address are served one after the other.  A workgroup that
+// walks a long span of a root's two-paths therefore keeps a cache of counters
+// in LDS: a direct-mapped table of CYC_CACHE (vertex, count) slots; the first
+// vertex to reach an empty slot owns it for the rest of the span, vertices
+// that find their slot taken go to the global counter as before.  At the end
+// of the span a slot with count k is added to the global counter in one
+// atomic whose old value o stands for o*k + k(k-1)/2 new pairs of two-paths.
+#define CYC_CACHE 16384
+#define CYC_CACHE_BITS 14
+
+__device__ __forceinline__ uint32_t cyc_count_cached(uint32_t *cnt, int32_t *keys, uint32_t *cnts, int32_t v3) {
+    const uint32_t h = ((uint32_t)v3 * 2654435761u) >> (32 - CYC_CACHE_BITS);
+    int32_t k = keys[h];
+    if (k == -1) {
+        k = atomicCAS(keys + h, -1, v3);
+        if (k == -1) k = v3;
+    }
+    if (k == v3) {
+        atomicAdd(cnts + h, 1u);
+        return 0;
+    }
+    return atomicAdd(cnt + v3, 1u);
+}
+
+template <bool RESET, bool CACHE = false>
 __device__ __forceinline__ uint64_t cyc_wave_pass(const GraphView &g, const int64_t *wp, int32_t v1, int64_t blk0,
-                                                  int64_t bstep, uint32_t *cnt, uint32_t *s_pre, int64_t *s_beg) {
+                                                  int64_t bstep, uint32_t *cnt, uint32_t *s_pre, int64_t *s_beg,
+                                                  int64_t block = CYC_BLOCK, int64_t blk_end = INT64_MAX,
+                                                  int32_t *keys = nullptr, uint32_t *cnts = nullptr) {
     const int lane = lane_id();
     const int64_t *off = g.off[0];
     const int32_t *adj = g.adj[0];
     const int64_t lb = off[v1], le = g.mid[0][v1];
     const int64_t base = wp[lb], W = wp[le] - base;
-    const int64_t nblk = (W + CYC_BLOCK - 1) / CYC_BLOCK;
+    const int64_t nblk = min(blk_end, (W + block - 1) / block);
     uint64_t acc = 0;
     for (int64_t blk = blk0; blk < nblk; blk += bstep) {
-        int64_t w0 = blk * CYC_BLOCK;
-        const int64_t w1 = min(W, w0 + CYC_BLOCK);
+        int64_t w0 = blk * block;
+        const int64_t w1 = min(W, w0 + block);
         int64_t a = lb, ae = le;  // last arc a in [lb, le) with wp[a] - base <= w0
         while (ae - a > 1) {
             int64_t mid = a + ((ae - a) >> 1);
@@ -1566,6 +1595,7 @@ __device__ __forceinline__ uint64_t cyc_wave_pass(const GraphView &g, const int6
                 for (int u = 0; u < 4; ++u) {
                     if (v3[u] < 0) continue;
                     if (RESET) cnt[v3[u]] = 0;
+                    else if (CACHE) acc += cyc_count_cached(cnt, keys, cnts, v3[u]);
                     else acc += atomicAdd(cnt + v3[u], 1u);
                 }
             }
@@ -1578,9 +1608,9 @@ __device__ __forceinline__ uint64_t cyc_wave_pass(const GraphView &g, const int6
 
 // Light roots: one workgroup of 4 waves per root, roots taken from a queue
 // (index order = heaviest first); workgroup b owns the counter array
-// dense + (CYC_HEAVY_SLABS + b) * stride.  Roots whose cost exceeds heavy_thr
+// dense + b * stride.  Roots whose cost exceeds heavy_thr
 // are left to k_cycle4_heavy.
-#define CYC_HEAVY_SLABS 4
+#define CYC_HEAVY_GROUPS 3  // groups of counter arrays for heavy roots, one group per stream
 __global__ __launch_bounds__(256) void k_cycle4_light(GraphView g, const int64_t *wp, int64_t lo, int64_t hi,
                                                       const int64_t *cost, int64_t heavy_thr,
                                                       unsigned long long *queue, uint32_t *dense, int64_t stride,
@@ -1589,7 +1619,7 @@ __global__ __launch_bounds__(256) void k_cycle4_light(GraphView g, const int64_t
     __shared__ int64_t s_beg[4][GPM_WAVE];
     __shared__ long long s_next;
     const int wave = threadIdx.x / GPM_WAVE, lane = lane_id();
-    uint32_t *cnt = dense + (size_t)(blockIdx.x + CYC_HEAVY_SLABS) * (size_t)stride;
+    uint32_t *cnt = dense + (size_t)blockIdx.x * (size_t)stride;
     uint64_t acc = 0, bytes = 0;
     // roots are claimed in batches: one atomic per root on a single word would serialise a chunk of a
     // million light roots
@@ -1637,19 +1667,22 @@ __global__ __launch_bounds__(256) void k_cycle4_light(GraphView g, const int64_t
             ++i;
             continue;
         }
-        __threadfence();  // the zeros of the last root are in place before this root counts
+        // The zeros of the last root are in place before this root counts.  The array belongs to this
+        // workgroup alone, so workgroup scope is enough (the barrier carries it): stores and atomics both
+        // complete in L2, and a wider fence would write the whole L2 back once per root.
         __syncthreads();
         const int32_t v1 = (int32_t)(g.n - 1 - i);
-        acc += cyc_wave_pass<false>(g, wp, v1, wave, 4, cnt, s_pre[wave], s_beg[wave]);
+        // four blocks at least, so that every wave of the workgroup has two-paths to walk
+        const int64_t blk = min((int64_t)CYC_BLOCK, max((int64_t)256, (((paths + 3) >> 2) + 255) & ~(int64_t)255));
+        acc += cyc_wave_pass<false>(g, wp, v1, wave, 4, cnt, s_pre[wave], s_beg[wave], blk);
         // bytes of this root: its list and one prefix per arc, every two-path read and counted
         if (threadIdx.x == 0) bytes += 8ull * (uint64_t)paths + 4ull + 12ull * (uint64_t)(g.mid[0][v1] - g.off[0][v1]);
-        __threadfence();
         __syncthreads();
         if (paths * 8 >= (int64_t)v1) {  // zero [0, v1) with coalesced stores
             uint4 *z = reinterpret_cast<uint4 *>(cnt);
             for (int x = threadIdx.x; x < (v1 + 3) / 4; x += 256) z[x] = make_uint4(0u, 0u, 0u, 0u);
         } else {
-            cyc_wave_pass<true>(g, wp, v1, wave, 4, cnt, s_pre[wave], s_beg[wave]);
+            cyc_wave_pass<true>(g, wp, v1, wave, 4, cnt, s_pre[wave], s_beg[wave], blk);
         }
         ++i;
     }
@@ -1661,17 +1694,59 @@ __global__ __launch_bounds__(256) void k_cycle4_light(GraphView g, const int64_t
     }
 }
 
-// Heavy root: the whole grid walks one root into counter array `cnt`; the
-// caller zeroes cnt[0, v1) afterwards.
-__global__ __launch_bounds__(256) void k_cycle4_heavy(GraphView g, const int64_t *wp, int32_t v1, uint32_t *cnt,
-                                                      unsigned long long *n_cycles, unsigned long long *alg_bytes) {
-    __shared__ uint32_t s_pre[4][GPM_WAVE];
-    __shared__ int64_t s_beg[4][GPM_WAVE];
+// Heavy roots, up to CYC_BATCH of them per launch (fewer when memory for the arrays is short), each with a counter array of
+// its own (root r of the batch: dense + r * stride; the caller zeroes them
+// afterwards).  A root is cut into spans of `span` two-paths, one workgroup of
+// 16 waves per span (workgroups wg0[r] .. wg0[r + 1] belong to root r); the
+// waves share the span's blocks of `block` two-paths and one LDS counter cache.
+// Dynamic LDS: s_beg[16][64] (int64) | s_pre[16][64] | keys[CYC_CACHE] | cnts[CYC_CACHE].
+#define CYC_BATCH 128
+#define CYC_HEAVY_WAVES 16
+struct CycBatch {
+    int32_t n;
+    int32_t v1[CYC_BATCH];
+    int32_t wg0[CYC_BATCH + 1];
+};
+#define CYC_HEAVY_LDS_BYTES (CYC_HEAVY_WAVES * GPM_WAVE * 12 + CYC_CACHE * 8)
+
+__global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_heavy(GraphView g, const int64_t *wp, CycBatch b,
+                                                                           uint32_t *dense, int64_t stride,
+                                                                           int64_t span, int64_t block,
+                                                                           unsigned long long *n_cycles,
+                                                                           unsigned long long *alg_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    int64_t *s_beg = reinterpret_cast<int64_t *>(smem);
+    uint32_t *s_pre = smem + CYC_HEAVY_WAVES * GPM_WAVE * 2;
+    int32_t *keys = reinterpret_cast<int32_t *>(s_pre + CYC_HEAVY_WAVES * GPM_WAVE);
+    uint32_t *cnts = reinterpret_cast<uint32_t *>(keys) + CYC_CACHE;
     const int wave = threadIdx.x / GPM_WAVE, lane = lane_id();
-    uint64_t acc = cyc_wave_pass<false>(g, wp, v1, (int64_t)blockIdx.x * 4 + wave, (int64_t)gridDim.x * 4, cnt,
-                                        s_pre[wave], s_beg[wave]);
+    int r = 0;  // last root with wg0[r] <= blockIdx.x
+    for (int hi = b.n; hi - r > 1;) {
+        const int m = (r + hi) >> 1;
+        if (b.wg0[m] <= (int)blockIdx.x) r = m;
+        else hi = m;
+    }
+    const int32_t v1 = b.v1[r];
+    const int64_t sidx = (int64_t)blockIdx.x - b.wg0[r];
+    uint32_t *cnt = dense + (size_t)r * (size_t)stride;
+    for (int x = threadIdx.x; x < CYC_CACHE; x += blockDim.x) {
+        keys[x] = -1;
+        cnts[x] = 0;
+    }
+    __syncthreads();
+    const int64_t per_span = span / block;  // span is a multiple of block
+    uint64_t acc = cyc_wave_pass<false, true>(g, wp, v1, sidx * per_span + wave, CYC_HEAVY_WAVES, cnt,
+                                              s_pre + wave * GPM_WAVE, s_beg + wave * GPM_WAVE, block,
+                                              (sidx + 1) * per_span, keys, cnts);
+    __syncthreads();
+    for (int x = threadIdx.x; x < CYC_CACHE; x += blockDim.x) {
+        const uint32_t k = cnts[x];
+        if (k == 0) continue;
+        const uint64_t old = atomicAdd(cnt + keys[x], k);
+        acc += old * k + (uint64_t)k * (k - 1) / 2;
+    }
     uint64_t bytes = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (sidx == 0 && threadIdx.x == 0) {
         const int64_t lb = g.off[0][v1], le = g.mid[0][v1];
         bytes = 8ull * (uint64_t)(wp[le] - wp[lb]) + 4ull + 12ull * (uint64_t)(le - lb);
     }
