@@ -1777,6 +1777,9 @@ static int device_search(const SearchArgs &a, DevState &d) {
         HIP_TRY(hipStreamSynchronize(s));
     }
     uint64_t seq = 0, cyc_heavy_seq = 0;
+    // chunks in flight on the clique path; 1 runs every launch with the GPU to itself (kernel times
+    // then add up to the wall time, which is how a kernel's own rate is measured)
+    const int clq_inflight = (int)std::min<int64_t>(CLQ_INFLIGHT, std::max<int64_t>(1, env_i64("GPM_CLIQUE_INFLIGHT", CLQ_INFLIGHT)));
     const auto t_begin = std::chrono::steady_clock::now();
     while (!ctx->stop) {
         const uint64_t c = claim_chunk(ctx);
@@ -1837,7 +1840,7 @@ static int device_search(const SearchArgs &a, DevState &d) {
             continue;
         }
         if (clique) {
-            ChunkSlot &sl = d.slots[seq++ % CLQ_INFLIGHT];
+            ChunkSlot &sl = d.slots[seq++ % clq_inflight];
             if (sl.busy) {  // at most CLQ_INFLIGHT chunks ahead of the GPU
                 HIP_TRY(hipEventSynchronize(sl.done));
                 sl.busy = false;
