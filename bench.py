@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--scale", type=int, default=None, help="override the R-MAT scale of the configuration")
     ap.add_argument("--pattern", default=None, help="override the pattern of the configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-search", action="store_true",
+                    help="skip the untimed search with one chunk in flight (profiling runs: its launches would "
+                         "mix into the per-kernel averages of the timed steps)")
     ap.add_argument("--cpu-ranks", type=int, default=0,
                     help="also time the reference under mpirun -np K (K >= 3) on the twin; off by default, it is slow")
     args = ap.parse_args()
@@ -254,7 +257,8 @@ def main():
     # the GPU to itself.  In the timed steps up to four chunks overlap and a launch's duration includes
     # the time its workgroups share the compute units with other kernels.
     alone = None
-    if rank == 0 and world == 1 and CONFIGS[args.config]["pattern"].startswith("clique") and args.pattern is None:
+    if (rank == 0 and world == 1 and CONFIGS[args.config]["pattern"].startswith("clique") and args.pattern is None
+            and not args.no_extra_search):
         os.environ["GPM_CLIQUE_INFLIGHT"] = "1"
         gdist.reset_cursor(cursor)
         t1 = time.perf_counter()

@@ -9,7 +9,7 @@ TAG=${1:-r1}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-search"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BENCH > "$OUT/trace.json" 2> "$OUT/trace.err" || exit 1
 echo "trace done"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o t -- $BENCH > "$OUT/fetch.json" 2> "$OUT/fetch.err" || exit 1
