@@ -142,7 +142,65 @@ int buildPlan(const Pattern *p, int flags, gpm_plan *plan, char *err, int errLen
     int num[MAX_MATCH_SIZE] = {0};
     int32_t par0[MAX_MATCH_SIZE];
     int root = (!keepReference && P > 2 && nbrs[0] == 1) ? someNbr[0] : 0;
-    if (numberFrom(p, root, -1, 1, num, par0, 0) != P)
+
+    /* Twins -- two vertices that are not adjacent, carry the same label and have exactly the same
+     * arcs to and from every other vertex -- are bound last as well when the pattern has no leaves:
+     * their candidates are then one common set, counted as pairs in closed form, instead of one
+     * extension level per twin.  The numbering runs over the other vertices only (they must stay
+     * connected) and each twin hangs off its first neighbour. */
+    int twinA = -1, twinB = -1;
+    if (!keepReference && P >= 4) {
+        int leaves = 0;
+        for (int v = 0; v < P; ++v) leaves += nbrs[v] == 1;
+        unsigned char arc[MAX_MATCH_SIZE][MAX_MATCH_SIZE];
+        memset(arc, 0, sizeof arc);
+        for (int v = 0; v < P; ++v)
+            for (int j = 0; j < p->outDegrees[v]; ++j)
+                if (p->outEdges[v][j] != v) arc[v][p->outEdges[v][j]] = 1;
+        for (int a = P - 1; a >= 1 && twinA < 0 && leaves == 0; --a)
+            for (int b = a - 1; b >= 0 && twinA < 0; --b) {
+                if (arc[a][b] || arc[b][a] || nbrs[a] == 0) continue;
+                if (p->hasLabels && p->labels[a] != p->labels[b]) continue;
+                int same = 1;
+                for (int t = 0; t < P && same; ++t)
+                    if (t != a && t != b) same = arc[a][t] == arc[b][t] && arc[t][a] == arc[t][b];
+                if (!same) continue;
+                /* the rest must be connected from the root the search would use */
+                int r = root;
+                if (r == a || r == b) r = someNbr[r];
+                int tmpNum[MAX_MATCH_SIZE] = {0};
+                int32_t tmpPar[MAX_MATCH_SIZE];
+                tmpNum[a] = tmpNum[b] = MAX_MATCH_SIZE + 1;
+                if (numberFrom(p, r, -1, 1, tmpNum, tmpPar, 0) != P - 2) continue;
+                twinA = b; /* the lower pattern vertex first */
+                twinB = a;
+                root = r;
+            }
+    }
+    if (twinA >= 0) {
+        num[twinA] = num[twinB] = MAX_MATCH_SIZE + 1; /* not to be entered by the numbering */
+        if (numberFrom(p, root, -1, 1, num, par0, 0) != P - 2)
+            return planFail(err, errLen, "pattern is not connected from vertex 1");
+        int id = P - 2;
+        const int tw[2] = {twinA, twinB};
+        for (int k = 0; k < 2; ++k) {
+            int v = tw[k], parent = -1, inEdge = 0;
+            for (int w = 0; w < P && parent < 0; ++w) { /* first neighbour that lists v, else that v lists */
+                if (w == twinA || w == twinB) continue;
+                for (int j = 0; j < p->outDegrees[w] && parent < 0; ++j)
+                    if (p->outEdges[w][j] == v) parent = w;
+            }
+            if (parent < 0)
+                for (int j = 0; j < p->outDegrees[v] && parent < 0; ++j)
+                    if (p->outEdges[v][j] != v) {
+                        parent = p->outEdges[v][j];
+                        inEdge = 1;
+                    }
+            ++id;
+            num[v] = inEdge ? -id : id;
+            par0[v] = parent;
+        }
+    } else if (numberFrom(p, root, -1, 1, num, par0, 0) != P)
         return planFail(err, errLen, "pattern is not connected from vertex 1");
     int seq[MAX_MATCH_SIZE], viaIn[MAX_MATCH_SIZE];
     for (int v = 0; v < P; ++v) {
