@@ -704,17 +704,21 @@ struct LeafSuffix {
     int8_t cls_of[GPM_MAXP], grp_of[GPM_MAXP];  // class and group of every leaf level
 };
 
-__device__ __forceinline__ __int128 falling128(long long x, int k) {
-    __int128 r = 1;
-    for (int i = 0; i < k; ++i) r *= (x - i > 0 ? x - i : 0);
+// Arithmetic modulo 2^128 (unsigned): sums, differences and products stay exact modulo 2^64 however
+// large the true values are; only the divisions by a factorial below need the true value to fit.
+typedef unsigned __int128 u128;
+
+__device__ __forceinline__ u128 falling128(long long x, int k) {
+    u128 r = 1;
+    for (int i = 0; i < k; ++i) r *= (u128)(x - i > 0 ? x - i : 0);
     return r;
 }
 
 // Ways to bind a leaves off s1 and b leaves off s2 (see above), ordered tuples.
-__device__ __forceinline__ __int128 leaf_ways(long long A, long long B, long long t, int a, int b) {
+__device__ __forceinline__ u128 leaf_ways(long long A, long long B, long long t, int a, int b) {
     if (b == 0) return falling128(A, a);
     if (a == 0) return falling128(B, b);
-    __int128 sum = 0;
+    u128 sum = 0;
     long long binom_a = 1, binom_b = 1, jfact = 1;
     for (int j = 0; j <= a && j <= b; ++j) {
         if (j > 0) {
@@ -722,11 +726,32 @@ __device__ __forceinline__ __int128 leaf_ways(long long A, long long B, long lon
             binom_b = binom_b * (b - j + 1) / j;
             jfact *= j;
         }
-        __int128 term = (__int128)(binom_a * binom_b * jfact) * falling128(t, j) * falling128(A - j, a - j) *
-                        falling128(B - j, b - j);
-        sum += (j & 1) ? -term : term;
+        const u128 term = (u128)(binom_a * binom_b * jfact) * falling128(t, j) * falling128(A - j, a - j) *
+                          falling128(B - j, b - j);
+        if (j & 1) sum -= term;
+        else sum += term;
     }
     return sum;
+}
+
+// C(x, k) without ever holding more than the result times k: the falling factorial of a hub's degree
+// overflows 128 bits from k = 7 on, the binomial itself does not.
+__device__ __forceinline__ u128 binom128(long long x, int k) {
+    if (x < k) return 0;
+    u128 r = 1;
+    for (int i = 1; i <= k; ++i) {
+        long long num = x - k + i, den = i;  // r = C(x-k+i-1, i-1) so far; r * num / den is an integer
+        long long a = num, b = den;
+        while (b) {
+            const long long t = a % b;
+            a = b;
+            b = t;
+        }
+        num /= a;
+        den /= a;
+        r = r / (u128)den * (u128)num;  // den divides r: it is coprime to num and divides r * num
+    }
+    return r;
 }
 
 __device__ __forceinline__ long long small_factorial(int k) {
@@ -786,14 +811,20 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_leaf_suffix(GraphView 
         }
         if (lane != 0) continue;
         bytes += 4ull * (uint64_t)S;
-        unsigned __int128 ways = 1;
+        u128 ways = 1;
         for (int c = 0; c < ls.n_cls; ++c) {
             const LeafClass &lc = ls.cls[c];
             const int a = lc.cnt[0], b = lc.n_grp > 1 ? lc.cnt[1] : 0;
-            __int128 w = leaf_ways(A[c], B[c], T[c], a, b);
-            if (lc.ordered[0]) w /= small_factorial(a);
-            if (lc.n_grp > 1 && lc.ordered[1]) w /= small_factorial(b);
-            ways *= (unsigned __int128)(w > 0 ? w : 0);
+            u128 w;
+            if (b == 0 && lc.ordered[0]) {
+                w = binom128(A[c], a);
+            } else {
+                w = leaf_ways(A[c], B[c], T[c], a, b);
+                // the divisions are exact while |A|^a |B|^b stays below 2^128
+                if (lc.ordered[0]) w /= (u128)small_factorial(a);
+                if (lc.n_grp > 1 && lc.ordered[1]) w /= (u128)small_factorial(b);
+            }
+            ways *= w;
         }
         cnt += (uint64_t)ways;
     }

@@ -478,6 +478,29 @@ def test_leaf_suffix_closed_form(pname, monkeypatch):
                     assert got[0] == want, (pname, pl, symbreak, got, want)
 
 
+def test_star_counts_of_a_hub_are_exact_modulo_2_64():
+    """A star with 7 leaves around a hub of degree 300 000: the falling factorial of the degree does
+    not fit 128 bits, the count (far above 2^64) must still be exact modulo 2^64, with the leaves
+    ordered by symmetry breaking (binomial times 7!) and without (falling factorial)."""
+    deg = 300_000
+    n = deg + 1
+    hub = np.zeros(deg, dtype=np.int32)
+    leaves = np.arange(1, n, dtype=np.int32)
+    s, d = np.concatenate([hub, leaves]), np.concatenate([leaves, hub])
+    order = np.lexsort((d, s))
+    s, d = s[order], d[order]
+    pat = (8, _und([(1, k) for k in range(2, 9)]))
+    want = 1
+    for i in range(7):
+        want *= deg - i
+    m = binding.Matcher(1)
+    upload(m, n, s, d)
+    for symbreak in (True, False):
+        m.set_pattern(pat, symbreak=symbreak)
+        assert m.findMatches(count_only=True) == want % (1 << 64), symbreak
+    m.close()
+
+
 TWINNED = {
     "k23": (5, _und([(a, b) for a in (1, 2) for b in (3, 4, 5)])),
     "tailed_k23": (5, _und([(1, 2), (1, 3), (2, 4), (3, 4), (2, 5), (3, 5)])),
