@@ -14,7 +14,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <array>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -145,6 +147,7 @@ struct DevState {
     int64_t cyc_stride = 0;
     int cyc_blocks = 0;
     int cyc_batch = 1;     // heavy roots per launch
+    LeafTerm *ls_terms = nullptr;  // inclusion-exclusion terms of the leaf-suffix kernel
     unsigned long long *cyc_queue = nullptr;
     std::vector<EventPair> events;
     size_t events_used = 0;
@@ -375,6 +378,8 @@ extern "C" void gpm_hip_destroy(gpm_ctx *ctx) {
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         free_graph(d);
         free_buffers(d);
+        dev_free(d.ls_terms);
+        d.ls_terms = nullptr;
         for (auto &ev : d.events) {
             (void)hipEventDestroy(ev.a);
             (void)hipEventDestroy(ev.b);
@@ -930,7 +935,7 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
             for (int i = 0; i < lc.n_grp; ++i)
                 if (lc.src[i] == lv.src_level) gi = i;
             if (gi < 0) {
-                if (lc.n_grp == 2) { ok = false; break; }
+                if (lc.n_grp == 3) { ok = false; break; }
                 gi = lc.n_grp++;
                 lc.src[gi] = lv.src_level;
                 lc.level0[gi] = (int8_t)k;
@@ -963,6 +968,64 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
             for (int j = 0; j < pv.lv[k].n_lower && ok; ++j)
                 if (pv.lv[k].lower_level[j] >= S) ok = k >= S && ls.cls_of[k] == ls.cls_of[pv.lv[k].lower_level[j]] &&
                                                        ls.grp_of[k] == ls.grp_of[pv.lv[k].lower_level[j]];
+        // classes of three groups: the terms of the inclusion-exclusion over the set partitions of their leaves
+        std::vector<LeafTerm> terms;
+        for (int c = 0; c < ls.n_cls && ok; ++c) {
+            LeafClass &lc = ls.cls[c];
+            if (lc.n_grp < 3) continue;
+            std::vector<int> grp;  // group of every leaf of the class
+            for (int gi = 0; gi < 3; ++gi) grp.insert(grp.end(), (size_t)lc.cnt[gi], gi);
+            const int q = (int)grp.size();
+            std::map<std::array<uint8_t, 8>, long long> sum;
+            std::vector<int> blk((size_t)q, 0);  // restricted growth string: block of every leaf
+            for (;;) {
+                int nb = 0;
+                for (int b : blk) nb = std::max(nb, b + 1);
+                int mask[GPM_MAXP] = {0}, size[GPM_MAXP] = {0};
+                for (int i = 0; i < q; ++i) {
+                    mask[blk[(size_t)i]] |= 1 << grp[(size_t)i];
+                    size[blk[(size_t)i]]++;
+                }
+                long long coef = 1;
+                std::array<uint8_t, 8> e{};
+                for (int b = 0; b < nb; ++b) {
+                    long long f = 1;
+                    for (int i = 2; i < size[b]; ++i) f *= i;  // (size - 1)!
+                    coef *= (size[b] % 2 ? f : -f);
+                    e[(size_t)mask[b]]++;
+                }
+                sum[e] += coef;
+                // next restricted growth string
+                int i = q - 1;
+                for (; i > 0; --i) {
+                    int mx = 0;
+                    for (int j = 0; j < i; ++j) mx = std::max(mx, blk[(size_t)j]);
+                    if (blk[(size_t)i] <= mx) break;
+                }
+                if (i == 0) break;
+                blk[(size_t)i]++;
+                for (int j = i + 1; j < q; ++j) blk[(size_t)j] = 0;
+            }
+            lc.term_beg = (int16_t)terms.size();
+            for (const auto &kv : sum)
+                if (kv.second) {
+                    LeafTerm t{};
+                    t.coef = kv.second;
+                    for (int k = 0; k < 8; ++k) t.e[k] = kv.first[(size_t)k];
+                    terms.push_back(t);
+                }
+            lc.term_end = (int16_t)terms.size();
+            ok = terms.size() < 30000;
+        }
+        for (auto &d : ctx->devs) {
+            HIP_TRY(hipSetDevice(d.dev));
+            dev_free(d.ls_terms);
+            d.ls_terms = nullptr;
+            if (ok && !terms.empty()) {
+                HIP_TRY(hipMalloc(&d.ls_terms, terms.size() * sizeof(LeafTerm)));
+                HIP_TRY(hipMemcpy(d.ls_terms, terms.data(), terms.size() * sizeof(LeafTerm), hipMemcpyHostToDevice));
+            }
+        }
         ls.enabled = ok;
         ls.S = (int8_t)S;
     }
@@ -1285,7 +1348,7 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
         const unsigned blocks = (unsigned)std::min<int64_t>((nrows + TAIL_WAVES - 1) / TAIL_WAVES, 16384);
         int rc = timed_begin(d, GPM_KIND_TAIL, nrows);
         if (rc) return rc;
-        k_leaf_suffix<<<blocks, TAIL_WAVES * GPM_WAVE, 0, s>>>(d.gv, ctx->pv, ctx->ls, rows, nrows,
+        k_leaf_suffix<<<blocks, TAIL_WAVES * GPM_WAVE, 0, s>>>(d.gv, ctx->pv, ctx->ls, d.ls_terms, rows, nrows,
                                                               d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_TAIL_BYTES);
         HIP_TRY(hipGetLastError());
         return timed_end(d);

@@ -687,7 +687,8 @@ __global__ void k_label_segments(GraphView g, const uint32_t *labcnt, uint32_t *
 //     W(a, b) = sum_j (-1)^j C(a,j) C(b,j) j! t^(j) (|A|-j)^(a-j) (|B|-j)^(b-j)
 // (x^(k) = falling factorial; the sum runs over the numbers j of leaf pairs
 // forced onto a common vertex), divided by a! or b! when ordering bounds make
-// the leaves of a group interchangeable.  Only t needs a list intersection,
+// the leaves of a group interchangeable.  Three groups per label go through the
+// general inclusion-exclusion over set partitions (LeafTerm below).  Only t needs a list intersection,
 // one per partial match of the inner vertices instead of one partial match per
 // leaf binding.  Counts are taken modulo 2^64 like every other count here.
 // Algorithmic bytes: the row, the degree lookups and both operands of the
@@ -695,8 +696,18 @@ __global__ void k_label_segments(GraphView g, const uint32_t *labcnt, uint32_t *
 
 struct LeafClass {
     int32_t label;                 // -1: unlabelled
-    int8_t n_grp;                  // 1 or 2 groups
-    int8_t src[2], cnt[2], ordered[2], level0[2];  // inner level, leaves, bounds make them a chain, first leaf level
+    int8_t n_grp;                  // 1 to 3 groups
+    int8_t src[3], cnt[3], ordered[3], level0[3];  // inner level, leaves, bounds make them a chain, first leaf level
+    int16_t term_beg, term_end;    // three groups: this class's terms in the term table (see LeafTerm)
+};
+// Three groups A1, A2, A3 of one label: the ordered bindings without a clash are
+//     sum over the set partitions pi of the leaves of  mu(pi) * prod over blocks B of pi of n[G(B)],
+// mu(pi) = prod (-1)^(|B|-1) (|B|-1)!, G(B) = the groups the leaves of B belong to (a bit mask), and
+// n[T] = number of free vertices common to the groups of T.  The host adds up the partitions that give
+// the same product: a term is a coefficient and the exponent of every n[T], T = 1..7.
+struct LeafTerm {
+    long long coef;
+    uint8_t e[8];
 };
 struct LeafSuffix {
     int8_t enabled, S, n_cls;
@@ -762,71 +773,98 @@ __device__ __forceinline__ long long small_factorial(int k) {
 
 // One wave per partial match of the S inner vertices.
 __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_leaf_suffix(GraphView g, PlanView pl, LeafSuffix ls,
-                                                                      const int32_t *rows, int64_t nrows,
-                                                                      unsigned long long *n_matches,
+                                                                      const LeafTerm *terms, const int32_t *rows,
+                                                                      int64_t nrows, unsigned long long *n_matches,
                                                                       unsigned long long *alg_bytes) {
     const int wave = threadIdx.x / GPM_WAVE, lane = lane_id();
     const int S = ls.S;
     uint64_t cnt = 0, bytes = 0;
     for (int64_t r = (int64_t)blockIdx.x * TAIL_WAVES + wave; r < nrows; r += (int64_t)gridDim.x * TAIL_WAVES) {
         const int32_t *m = rows + r * S;
-        long long A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0}, T[4] = {0, 0, 0, 0};
+        u128 ways = 1;  // meaningful in lane 0
+        if (lane == 0) bytes += 4ull * (uint64_t)S;
         for (int c = 0; c < ls.n_cls; ++c) {
             const LeafClass &lc = ls.cls[c];
-            const int32_t s1 = m[lc.src[0]];
-            A[c] = leaf_count(g, pl.lv[lc.level0[0]], m, S, s1);
+            const bool segs = lc.label >= 0 && g.adjL;
+            const int32_t *arr = segs ? g.adjL : g.adj[0];
+            // candidates of group i: the label's segment of its source's list when there is one (ids ascend
+            // inside it), else the whole list
+            int64_t lb[3] = {0, 0, 0}, le[3] = {0, 0, 0};
+            long long n1[3] = {0, 0, 0};  // free neighbours with the label
+            for (int i = 0; i < lc.n_grp; ++i) {
+                const int32_t si = m[lc.src[i]];
+                n1[i] = leaf_count(g, pl.lv[lc.level0[i]], m, S, si);
+                if (segs) {
+                    const uint32_t *q = g.labseg + (size_t)si * (size_t)(g.nlab + 1) + (size_t)lc.label;
+                    lb[i] = g.off[0][si] + q[0], le[i] = g.off[0][si] + q[1];
+                } else {
+                    lb[i] = g.off[0][si], le[i] = g.off[0][si + 1];
+                }
+            }
             if (lane == 0) bytes += 20ull * (uint64_t)lc.n_grp;  // two offsets and a label count per group
-            if (lc.n_grp < 2) continue;
-            const int32_t s2 = m[lc.src[1]];
-            B[c] = leaf_count(g, pl.lv[lc.level0[1]], m, S, s2);
-            // t: common free neighbours with the label -- walk the shorter list (its label segment when
-            // there is one: ids ascend inside it), look each entry up in the other
-            int64_t b1, e1, b2, e2;
-            const int32_t *arr = g.adj[0];
-            if (lc.label >= 0 && g.adjL) {
-                arr = g.adjL;
-                const uint32_t *g1 = g.labseg + (size_t)s1 * (size_t)(g.nlab + 1) + (size_t)lc.label;
-                const uint32_t *g2 = g.labseg + (size_t)s2 * (size_t)(g.nlab + 1) + (size_t)lc.label;
-                b1 = g.off[0][s1] + g1[0], e1 = g.off[0][s1] + g1[1];
-                b2 = g.off[0][s2] + g2[0], e2 = g.off[0][s2] + g2[1];
-            } else {
-                b1 = g.off[0][s1], e1 = g.off[0][s1 + 1];
-                b2 = g.off[0][s2], e2 = g.off[0][s2 + 1];
-            }
-            if (e2 - b2 < e1 - b1) {
-                int64_t x = b1; b1 = b2; b2 = x;
-                x = e1; e1 = e2; e2 = x;
-            }
-            if (lane == 0) bytes += 4ull * (uint64_t)((e1 - b1) + (e2 - b2));  // both operands, merge model
-            uint32_t common = 0;
-            for (int64_t i = b1 + lane; i < e1; i += GPM_WAVE) {
-                const int32_t v = arr[i];
-                if (lc.label >= 0 && !g.adjL && g.label[v] != (uint8_t)lc.label) continue;
-                bool in = contains_g(arr, b2, e2, v);
-                for (int t = 0; t < S && in; ++t) in = m[t] != v;  // bound vertices are not free
-                common += in;
-            }
-            T[c] = (long long)wave_sum_u64(common);
-            T[c] = __shfl(T[c], 0, GPM_WAVE);
-        }
-        if (lane != 0) continue;
-        bytes += 4ull * (uint64_t)S;
-        u128 ways = 1;
-        for (int c = 0; c < ls.n_cls; ++c) {
-            const LeafClass &lc = ls.cls[c];
-            const int a = lc.cnt[0], b = lc.n_grp > 1 ? lc.cnt[1] : 0;
-            u128 w;
-            if (b == 0 && lc.ordered[0]) {
-                w = binom128(A[c], a);
-            } else {
-                w = leaf_ways(A[c], B[c], T[c], a, b);
+            // free vertices of list x that are also in list y (and in list z, and in both): lanes over x
+            auto common = [&](int x, int y, int z, long long &cxy, long long &cxz, long long &cxyz) {
+                uint32_t a = 0, b = 0, ab = 0;
+                for (int64_t i = lb[x] + lane; i < le[x]; i += GPM_WAVE) {
+                    const int32_t v = arr[i];
+                    if (lc.label >= 0 && !segs && g.label[v] != (uint8_t)lc.label) continue;
+                    bool free_v = true;
+                    for (int t = 0; t < S && free_v; ++t) free_v = m[t] != v;  // bound vertices are not free
+                    if (!free_v) continue;
+                    const bool iy = contains_g(arr, lb[y], le[y], v);
+                    const bool iz = z >= 0 && contains_g(arr, lb[z], le[z], v);
+                    a += iy;
+                    b += iz;
+                    ab += iy && iz;
+                }
+                cxy = (long long)__shfl(wave_sum_u64(a), 0, GPM_WAVE);
+                cxz = (long long)__shfl(wave_sum_u64(b), 0, GPM_WAVE);
+                cxyz = (long long)__shfl(wave_sum_u64(ab), 0, GPM_WAVE);
+                if (lane == 0)  // merge model: every operand once
+                    bytes += 4ull * (uint64_t)((le[x] - lb[x]) + (le[y] - lb[y]) + (z >= 0 ? le[z] - lb[z] : 0));
+            };
+            u128 w = 0;
+            if (lc.n_grp == 1) {
+                w = lc.ordered[0] ? binom128(n1[0], lc.cnt[0]) : falling128(n1[0], lc.cnt[0]);
+            } else if (lc.n_grp == 2) {
+                const int x = le[1] - lb[1] < le[0] - lb[0] ? 1 : 0;
+                long long t = 0, unused1, unused2;
+                common(x, 1 - x, -1, t, unused1, unused2);
+                w = leaf_ways(n1[0], n1[1], t, lc.cnt[0], lc.cnt[1]);
                 // the divisions are exact while |A|^a |B|^b stays below 2^128
-                if (lc.ordered[0]) w /= (u128)small_factorial(a);
-                if (lc.n_grp > 1 && lc.ordered[1]) w /= (u128)small_factorial(b);
+                if (lc.ordered[0]) w /= (u128)small_factorial(lc.cnt[0]);
+                if (lc.ordered[1]) w /= (u128)small_factorial(lc.cnt[1]);
+            } else {
+                int x = 0;  // the shortest list is walked against the two others, then the shorter of those
+                for (int i = 1; i < 3; ++i)
+                    if (le[i] - lb[i] < le[x] - lb[x]) x = i;
+                int y = (x + 1) % 3, z = (x + 2) % 3;
+                if (le[z] - lb[z] < le[y] - lb[y]) {
+                    const int t = y;
+                    y = z;
+                    z = t;
+                }
+                long long n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cyz, unused1, unused2;
+                common(x, y, z, n[(1 << x) | (1 << y)], n[(1 << x) | (1 << z)], n[7]);
+                common(y, z, -1, cyz, unused1, unused2);
+                n[(1 << y) | (1 << z)] = cyz;
+                n[1] = n1[0], n[2] = n1[1], n[4] = n1[2];
+                if (lane == 0) {
+                    for (int t = lc.term_beg; t < lc.term_end; ++t) {
+                        const LeafTerm tm = terms[t];
+                        u128 prod = (u128)(tm.coef < 0 ? -tm.coef : tm.coef);
+                        for (int k = 1; k < 8; ++k)
+                            for (int e = 0; e < tm.e[k]; ++e) prod *= (u128)n[k];
+                        if (tm.coef < 0) w -= prod;
+                        else w += prod;
+                    }
+                    for (int i = 0; i < 3; ++i)
+                        if (lc.ordered[i]) w /= (u128)small_factorial(lc.cnt[i]);
+                }
             }
             ways *= w;
         }
-        cnt += (uint64_t)ways;
+        if (lane == 0) cnt += (uint64_t)ways;
     }
     cnt = wave_sum_u64(cnt);
     bytes = wave_sum_u64(bytes);

@@ -434,6 +434,10 @@ LEAFY = {
     "tri_leaves6": (6, _und([(1, 2), (2, 3), (1, 3), (1, 4), (1, 5), (2, 6)])),
     "tri_leaves7": (7, _und([(1, 2), (2, 3), (1, 3), (1, 4), (1, 5), (2, 6), (2, 7)])),
     "cyc_leaves6": (6, _und([(1, 2), (2, 3), (3, 4), (4, 1), (1, 5), (3, 6)])),
+    "spider7": (7, _und([(1, 2), (1, 3), (1, 4), (2, 5), (3, 6), (4, 7)])),
+    "cat_211": (7, _und([(1, 2), (2, 3), (1, 4), (1, 5), (2, 6), (3, 7)])),
+    "cat_221": (8, _und([(1, 2), (2, 3), (1, 4), (1, 5), (2, 6), (2, 7), (3, 8)])),
+    "tri_leaves_111": (6, _und([(1, 2), (2, 3), (1, 3), (1, 4), (2, 5), (3, 6)])),
 }
 LEAFY_LABELS = {
     "star5": [[0, 1, 1, 1, 1], [0, 1, 1, 2, 2], [1, 0, 1, 2, 0]],
@@ -445,13 +449,18 @@ LEAFY_LABELS = {
     "tri_leaves6": [[0, 0, 0, 1, 1, 1], [0, 1, 2, 2, 1, 2]],
     "tri_leaves7": [[0, 0, 1, 2, 2, 2, 2]],
     "cyc_leaves6": [[0, 1, 0, 1, 2, 2]],
+    "spider7": [[0, 1, 1, 1, 2, 2, 2], [0, 1, 2, 0, 2, 2, 1]],
+    "cat_211": [[0, 1, 2, 0, 0, 0, 0], [0, 1, 2, 1, 1, 2, 1]],
+    "cat_221": [[0, 0, 0, 1, 1, 1, 1, 1]],
+    "tri_leaves_111": [[0, 0, 0, 1, 1, 1], [0, 1, 2, 2, 2, 1]],
 }
 
 
 @pytest.mark.parametrize("pname", sorted(LEAFY))
 def test_leaf_suffix_closed_form(pname, monkeypatch):
     """Patterns whose last levels are all leaves (stars, double stars, brooms, a triangle or a
-    4-cycle with pendant vertices), unlabelled and with several labellings, symmetry breaking on
+    4-cycle with pendant vertices, caterpillars and spiders whose leaves of one label hang off three
+    inner vertices), unlabelled and with several labellings, symmetry breaking on
     and off: the count with the whole leaf suffix in closed form equals the count with that
     closed form switched off, and on a small graph both equal the oracle's enumeration."""
     pat = LEAFY[pname]
