@@ -313,6 +313,7 @@ def main():
                 "achieved": (alone["kernel_alg_bytes"][dom] / 1e9) / (alone["kernel_ms"][dom] / 1e3) if alone["kernel_ms"][dom] > 0 else 0.0,
                 "frac": ((alone["kernel_alg_bytes"][dom] / 1e9) / (alone["kernel_ms"][dom] / 1e3) / HBM_PEAK_GBS) if alone["kernel_ms"][dom] > 0 else 0.0,
                 "avg_launch_ms": alone["kernel_ms"][dom] / max(alone["kernel_launches"][dom], 1)},
+            "partial_matches_per_level_rank0": [int(x) for x in list(st.rows_in)[:plan.n_levels]],
             "search_ms_per_step_by_rank": [round(b / max(args.steps, 1), 3) for b in busy],
         }
         if world == 1 and not args.no_cpu_baseline:
