@@ -1682,7 +1682,8 @@ static int ensure_cycle4(gpm_ctx *ctx, DevState &d) {
     // the light workgroups' arrays
     const int64_t arrays = std::max<int64_t>(8, budget / (4 * d.cyc_stride));
     d.cyc_batch = (int)std::min<int64_t>(CYC_BATCH, std::max<int64_t>(1, arrays / 2 / CYC_HEAVY_GROUPS));
-    d.cyc_blocks = (int)std::min<int64_t>(2048, std::max<int64_t>(64, arrays - CYC_HEAVY_GROUPS * d.cyc_batch));
+    d.cyc_blocks = (int)std::min<int64_t>(env_i64("GPM_CYC_LIGHT_BLOCKS", 2048),
+                                          std::max<int64_t>(64, arrays - CYC_HEAVY_GROUPS * d.cyc_batch));
     const size_t dense_bytes = ((size_t)d.cyc_blocks + CYC_HEAVY_GROUPS * d.cyc_batch) * (size_t)d.cyc_stride * sizeof(uint32_t);
     HIP_TRY(hipMalloc(&d.cyc_cost, ((size_t)n + 1) * sizeof(int64_t)));
     HIP_TRY(hipMalloc(&d.cyc_wp, ((size_t)m + 2) * sizeof(int64_t)));
