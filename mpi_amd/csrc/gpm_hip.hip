@@ -1357,13 +1357,24 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
         if (!d.over_rows) HIP_TRY(hipMalloc(&d.over_rows, 2 * (size_t)d.cap_rows * sizeof(int64_t)));
         int64_t *over1 = d.over_rows, *over2 = d.over_rows + d.cap_rows;
         HIP_TRY(hipMemsetAsync(d.ctr + CTR_OVER, 0, 2 * sizeof(unsigned long long), s));
-        // 16 lanes and sets of up to 64 per partial match; what does not fit goes to whole waves with
-        // sets of up to 1024; what still does not fit goes level by level
-        unsigned blocks = (unsigned)std::min<int64_t>((nrows * 16 + 255) / 256, 1 << 16);
+        // 8 lanes and sets of up to 64 per partial match; what does not fit goes to 16 lanes with sets of up
+        // to 256, then to whole waves with sets of up to 1024; what still does not fit goes level by level
+        const int64_t grp = env_i64("GPM_FUSE3_GROUP", 8);
+        unsigned blocks = (unsigned)std::min<int64_t>((nrows * grp + 255) / 256, 1 << 16);
         int rc = timed_begin(d, GPM_KIND_TAIL, nrows);
         if (rc) return rc;
-        k_tail3<16, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, over1,
-                                              d.ctr + CTR_OVER, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_TAIL_BYTES);
+        if (grp == 4)
+            k_tail3<4, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, over1,
+                                                 d.ctr + CTR_OVER, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_TAIL_BYTES);
+        else if (grp == 8)
+            k_tail3<8, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, over1,
+                                                 d.ctr + CTR_OVER, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_TAIL_BYTES);
+        else if (grp == 32)
+            k_tail3<32, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, over1,
+                                                  d.ctr + CTR_OVER, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_TAIL_BYTES);
+        else
+            k_tail3<16, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, over1,
+                                                  d.ctr + CTR_OVER, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_TAIL_BYTES);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d))) return rc;
         uint64_t n_over = 0;
@@ -1372,15 +1383,28 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
         if (env_i64("GPM_FUSE3_WAVE", 1) == 0) {  // tests: straight to the level-by-level path
             over2 = over1;
         } else {
-        blocks = (unsigned)std::min<uint64_t>((n_over * 64 + 255) / 256, 1 << 16);
-        if ((rc = timed_begin(d, GPM_KIND_TAIL, (int64_t)n_over))) return rc;
-        k_tail3<64, 1024><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, over1, (int64_t)n_over, over2,
-                                                d.ctr + CTR_OVER + 1, d.ctr + CTR_TAIL_MATCHES,
-                                                d.ctr + CTR_TAIL_BYTES);
-        HIP_TRY(hipGetLastError());
-        if ((rc = timed_end(d))) return rc;
-        if ((rc = read_ctr(d, CTR_OVER + 1, &n_over))) return rc;
-        if (n_over == 0) return GPM_OK;
+            if (env_i64("GPM_FUSE3_MID", 1)) {  // sets of up to 256 with 16 lanes
+                blocks = (unsigned)std::min<uint64_t>((n_over * 16 + 255) / 256, 1 << 16);
+                if ((rc = timed_begin(d, GPM_KIND_TAIL, (int64_t)n_over))) return rc;
+                k_tail3<16, 256><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, over1, (int64_t)n_over,
+                                                       over2, d.ctr + CTR_OVER + 1, d.ctr + CTR_TAIL_MATCHES,
+                                                       d.ctr + CTR_TAIL_BYTES);
+                HIP_TRY(hipGetLastError());
+                if ((rc = timed_end(d))) return rc;
+                if ((rc = read_ctr(d, CTR_OVER + 1, &n_over))) return rc;
+                if (n_over == 0) return GPM_OK;
+                std::swap(over1, over2);  // over1: what is left; over2 free again
+                HIP_TRY(hipMemsetAsync(d.ctr + CTR_OVER + 1, 0, sizeof(unsigned long long), s));
+            }
+            blocks = (unsigned)std::min<uint64_t>((n_over * 64 + 255) / 256, 1 << 16);
+            if ((rc = timed_begin(d, GPM_KIND_TAIL, (int64_t)n_over))) return rc;
+            k_tail3<64, 1024><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, over1, (int64_t)n_over,
+                                                    over2, d.ctr + CTR_OVER + 1, d.ctr + CTR_TAIL_MATCHES,
+                                                    d.ctr + CTR_TAIL_BYTES);
+            HIP_TRY(hipGetLastError());
+            if ((rc = timed_end(d))) return rc;
+            if ((rc = read_ctr(d, CTR_OVER + 1, &n_over))) return rc;
+            if (n_over == 0) return GPM_OK;
         }
         // the partial matches whose sets did not fit a lane group: compact them to the front of this
         // frontier (through the next level's arena) and expand them level by level

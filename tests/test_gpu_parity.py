@@ -330,9 +330,13 @@ def test_three_fused_levels_equal_the_level_by_level_path(pname, monkeypatch):
     merge-model bytes of the level-by-level path."""
     n, s, d = util.build_graph({"graph": "rmat", "scale": 11, "ef": 8, "abcd": (0.7, 0.1, 0.1, 0.1), "seed": 1})
     got = []
-    for off, wave in (("1", "1"), ("0", "1"), ("0", "0")):  # off; lane groups then whole waves; lane groups then level by level
+    # off; lane groups of 8, then 16, then whole waves; without the middle tier and with groups of 16;
+    # lane groups then level by level
+    for off, wave, mid, grp in (("1", "1", "1", "8"), ("0", "1", "1", "8"), ("0", "1", "0", "16"), ("0", "0", "1", "8")):
         monkeypatch.setenv("GPM_NO_FUSE3", off)
         monkeypatch.setenv("GPM_FUSE3_WAVE", wave)
+        monkeypatch.setenv("GPM_FUSE3_MID", mid)
+        monkeypatch.setenv("GPM_FUSE3_GROUP", grp)
         m = binding.Matcher(1)
         upload(m, n, s, d)
         m.set_pattern(gen.PATTERNS[pname])
@@ -340,7 +344,7 @@ def test_three_fused_levels_equal_the_level_by_level_path(pname, monkeypatch):
         st = m.stats()
         got.append((c, st.alg_bytes))
         m.close()
-    assert got[0] == got[1] == got[2] and got[0][0] > 0
+    assert got[0] == got[1] == got[2] == got[3] and got[0][0] > 0
 
 
 def test_clique_kernel_equals_generic_path(monkeypatch):
