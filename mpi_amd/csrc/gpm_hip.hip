@@ -139,8 +139,9 @@ struct DevState {
     int64_t clq_stride = 0;
     int clq_scratch_blocks = 0;
     unsigned long long *clq_slots = nullptr;  // [0,CLQ_SLOTS) matches, [CLQ_SLOTS,2*CLQ_SLOTS) bytes
-    // 4-cycle path: two-path count of every root, counter arrays (slab 0 for heavy roots, one per
-    // workgroup of the light kernel), root queues of the light kernel's launches
+    // 4-cycle path: two-path count of every root, counter arrays (cyc_blocks of them for the workgroups of
+    // the light kernel, then CYC_HEAVY_GROUPS groups of cyc_batch for heavy roots), root queues of the light
+    // kernel's launches
     int64_t *cyc_cost = nullptr;
     int64_t *cyc_wp = nullptr;  // two-paths of all arcs before arc p (m + 1 entries)
     uint32_t *cyc_dense = nullptr;
@@ -181,7 +182,7 @@ struct gpm_ctx {
     bool use_clique = true;
     bool cycle4 = false;  // the plan is the 4-cycle with all 8 automorphisms folded
     bool use_cycle4 = true;
-    int64_t cyc_heavy_thr = 0;             // two-paths above which a root gets the whole GPU
+    int64_t cyc_heavy_thr = 0;             // two-paths from which a root is cut into spans (k_cycle4_heavy)
     std::vector<int64_t> cyc_heavy_roots;  // root indices at or above the threshold, ascending
     std::vector<int64_t> cyc_heavy_paths;  // their two-path counts
     int64_t chunk_roots = 1 << 20;  // upper bound of a chunk's size
