@@ -1585,7 +1585,7 @@ __global__ void k_cycle4_cost(GraphView g, const int64_t *wp, int64_t nroots, in
 // that more than a hundred others land on as well (hub to hub pairs), and
 // atomics on one address are served one after the other.  A workgroup that
 // walks a long span of a root's two-paths therefore keeps a cache of counters
-// in LDS: a direct-mapped table of CYC_CACHE (vertex, count) slots; the first
+// in LDS: a table of CYC_CACHE (vertex, count) slots, two neighbouring slots per vertex; the first
 // vertex to reach an empty slot owns it for the rest of the span, vertices
 // that find their slot taken go to the global counter as before.  At the end
 // of the span a slot with count k is added to the global counter in one
@@ -1594,15 +1594,18 @@ __global__ void k_cycle4_cost(GraphView g, const int64_t *wp, int64_t nroots, in
 #define CYC_CACHE_BITS 14
 
 __device__ __forceinline__ uint32_t cyc_count_cached(uint32_t *cnt, int32_t *keys, uint32_t *cnts, int32_t v3) {
-    const uint32_t h = ((uint32_t)v3 * 2654435761u) >> (32 - CYC_CACHE_BITS);
-    int32_t k = keys[h];
-    if (k == -1) {
-        k = atomicCAS(keys + h, -1, v3);
-        if (k == -1) k = v3;
-    }
-    if (k == v3) {
-        atomicAdd(cnts + h, 1u);
-        return 0;
+    uint32_t h = ((uint32_t)v3 * 2654435761u) >> (32 - CYC_CACHE_BITS);
+#pragma unroll
+    for (int way = 0; way < 2; ++way, h ^= 1u) {  // two neighbouring slots per vertex
+        int32_t k = keys[h];
+        if (k == -1) {
+            k = atomicCAS(keys + h, -1, v3);
+            if (k == -1) k = v3;
+        }
+        if (k == v3) {
+            atomicAdd(cnts + h, 1u);
+            return 0;
+        }
     }
     return atomicAdd(cnt + v3, 1u);
 }
