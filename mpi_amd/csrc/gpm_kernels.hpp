@@ -552,6 +552,15 @@ __global__ __launch_bounds__(256) void k_tail3(GraphView g, PlanView pl, TailInf
                 wl = j;
             }
         }
+        // neither Z nor the twins take a vertex at or below the smaller of their lower bounds: a long list
+        // is entered above it
+        if (we - wb > 4 * G) {
+            int32_t lo_z = -1, lo_b = -1;
+            for (int j = 0; j < lz.n_lower; ++j) lo_z = max(lo_z, m[lz.lower_level[j]]);
+            for (int j = 0; j < la.n_lower; ++j) lo_b = max(lo_b, m[la.lower_level[j]]);
+            const int32_t lo = min(lo_z, lo_b);
+            if (lo >= 0) wb = lower_bound_g(g.adj[0], wb, we, lo + 1);
+        }
         int nz = 0, nb = 0;
         for (int64_t i0 = wb; i0 < we && nz <= CAP && nb <= CAP; i0 += G) {
             const int64_t i = i0 + sub;
