@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void k_tail3(GraphView g, PlanView pl, TailInf
         }
         // neither Z nor the twins take a vertex at or below the smaller of their lower bounds: a long list
         // is entered above it
-        if (we - wb > 4 * G) {
+        if (we - wb > G) {
             int32_t lo_z = -1, lo_b = -1;
             for (int j = 0; j < lz.n_lower; ++j) lo_z = max(lo_z, m[lz.lower_level[j]]);
             for (int j = 0; j < la.n_lower; ++j) lo_b = max(lo_b, m[la.lower_level[j]]);
