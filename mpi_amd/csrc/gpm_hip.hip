@@ -1791,7 +1791,7 @@ static int prepare_chunks(gpm_ctx *ctx) {
     // the two-path counts are exact costs and every chunk is one persistent launch: few, large chunks
     if (cyc) want = std::max<int64_t>(1, want / 8);
     // the level-by-level path synchronises with the host several times per chunk: fewer, larger chunks
-    else if (!(ctx->clique_k && ctx->use_clique)) want = std::max<int64_t>(1, want / 4);
+    else if (!(ctx->clique_k && ctx->use_clique)) want = std::max<int64_t>(1, want / 8);
     const int64_t target = std::max<int64_t>(1, hpref.back() / want);
     int64_t begin = 0;
     while (begin < nroots) {
