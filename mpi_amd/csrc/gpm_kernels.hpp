@@ -320,6 +320,10 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
             }
         }
         const int32_t *wadj = walk < 0 ? sarr : g.adj[la.cons_dir[walk]];
+        if (walk >= 0 && e - b > GPM_WAVE) {  // a long list is entered and left at the bounds
+            if (lo_id >= 0) b = lower_bound_g(wadj, b, e, lo_id + 1);
+            if (hi_id != INT32_MAX) e = lower_bound_g(wadj, b, e, hi_id);
+        }
         if (ti.twin) {
             // levels A and B are twins: |S| survivors give |S|(|S|-1) ordered pairs, or
             // half of that when an ordering bound ties B to A; nothing is staged
@@ -477,6 +481,10 @@ __global__ __launch_bounds__(256) void k_tail_twin(GraphView g, PlanView pl, Tai
             for (int j = 0; j < la.n_upper; ++j) hi_id = min(hi_id, m[la.upper_level[j]]);
         }
         const int32_t *wadj = walk < 0 ? sarr : g.adj[la.cons_dir[walk]];
+        if (walk >= 0 && e - b > 4 * G) {  // a long list is entered and left at the bounds
+            if (lo_id >= 0) b = lower_bound_g(wadj, b, e, lo_id + 1);
+            if (hi_id != INT32_MAX) e = lower_bound_g(wadj, b, e, hi_id);
+        }
         uint32_t s_cnt = 0;
         for (int64_t i = b + sub; i < e; i += G) {
             const int32_t c = wadj[i];
