@@ -289,12 +289,12 @@ static void host_free(void *p) {
 
 static void free_graph(DevState &d) {
     (void)hipSetDevice(d.dev);
+    if (d.off[1] == d.off[0]) {  // symmetric graph: the in-CSR is an alias, not a second allocation
+        d.off[1] = nullptr;
+        d.adj[1] = nullptr;
+        d.mid[1] = nullptr;
+    }
     for (int dir = 0; dir < 2; ++dir) {
-        if (dir == 1 && d.off[1] == d.off[0]) {
-            d.off[1] = nullptr;
-            d.adj[1] = nullptr;
-            d.mid[1] = nullptr;
-        }
         dev_free(d.off[dir]);
         dev_free(d.adj[dir]);
         dev_free(d.mid[dir]);

@@ -649,6 +649,19 @@ def test_chunk_count_does_not_change_the_result():
     m.close()
 
 
+def test_a_context_takes_one_graph_after_another():
+    """Uploading a second and third graph into a context that has searched (symmetric, then directed,
+    then symmetric again) frees the first one's arrays exactly once and gives the golden counts."""
+    m = binding.Matcher(1)
+    for name in ("rmat10_clique4", "rand40_dir_rev4", "rmat8_cycle4", "rmat8_triangle"):
+        spec = next(g for g in GOLDEN if g["name"] == name)
+        n, s, d = util.build_graph(spec)
+        upload(m, n, s, d)
+        m.set_pattern(gen.PATTERNS[spec["pattern"]])
+        assert m.findMatches(count_only=True) == spec["count"], name
+    m.close()
+
+
 def test_bad_arguments_are_rejected():
     m = binding.Matcher(1)
     off = np.array([0, 2, 1], dtype=np.int64)  # not monotone
