@@ -156,8 +156,11 @@ void gpm_hip_destroy(gpm_ctx *ctx);
 /* Copy the data graph to every GPU of the context as CSR (replaces the
  * scatter of the graph over ranks, reference: distribiuteGraph / gatherGraph /
  * transpose, src/gpm-par.c:394-553).  Lists must be sorted ascending;
- * duplicates are kept.  in_off/in_adj may be NULL when the graph is symmetric
- * (the in-CSR then aliases the out-CSR).  labels may be NULL. */
+ * duplicates are kept.  in_off/in_adj may be NULL when every in-list equals
+ * the out-list of the same vertex entry for entry, duplicates included (the
+ * in-CSR then aliases the out-CSR); a graph that is symmetric only as a set of
+ * arcs but lists some arc more often than its reverse needs both.  labels may
+ * be NULL. */
 int gpm_hip_upload_graph(gpm_ctx *ctx, int32_t n,
                          const int64_t *out_off, const int32_t *out_adj,
                          const int64_t *in_off, const int32_t *in_adj,

@@ -60,7 +60,7 @@ class gpm_stats(ctypes.Structure):
                 ("kernel_alg_bytes", ctypes.c_uint64 * KINDS)]
 
 
-PLAN_SYMMETRIC_DATA, PLAN_BREAK_SYMMETRY, PLAN_DEGREE_FILTER = 1, 2, 4
+PLAN_SYMMETRIC_DATA, PLAN_BREAK_SYMMETRY, PLAN_DEGREE_FILTER, PLAN_REFERENCE_ORDER = 1, 2, 4, 8
 ROW_SINK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_uint64,
                             ctypes.c_int32)
 TEXT_SINK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64)
@@ -269,6 +269,8 @@ class Matcher:
             flags |= PLAN_DEGREE_FILTER
         if gi.simple and symbreak:
             flags |= PLAN_BREAK_SYMMETRY
+        if not gi.simple:  # duplicate arcs: which arcs are walked decides how often a match is reported
+            flags |= PLAN_REFERENCE_ORDER
         p = make_pattern(pattern, labels)
         try:
             plan = make_plan(p, flags)

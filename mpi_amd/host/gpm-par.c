@@ -129,13 +129,20 @@ int main(int argc, char *argv[]) {
 
     gpm_ctx *ctx;
     if (gpm_hip_create(ngpus, NULL, &ctx) != 0) die("GPU set-up failed", gpm_hip_last_error());
+    /* The in-CSR may be left out only when in-lists equal out-lists entry for entry.  `symmetric` says
+     * they are equal as sets; with duplicate arcs the multiplicities can differ, and a level reached
+     * over an in-edge walks the in-list with multiplicity (reference: src/gpm-par.c:205-213). */
+    int sameLists = graph->symmetric && graph->simple;
     if (gpm_hip_upload_graph(ctx, graph->nodesCount, graph->outOffsets, graph->outEdges,
-                             graph->symmetric ? NULL : graph->inOffsets, graph->symmetric ? NULL : graph->inEdges,
+                             sameLists ? NULL : graph->inOffsets, sameLists ? NULL : graph->inEdges,
                              graph->labels) != 0)
         die("graph upload failed", gpm_hip_last_error());
 
     int flags = 0;
-    if (graph->symmetric) flags |= PLAN_SYMMETRIC_DATA;
+    if (sameLists) flags |= PLAN_SYMMETRIC_DATA;
+    /* With duplicate arcs the number of times a match is printed depends on which pattern arcs are walked
+     * (with multiplicity) and which are membership tests: keep the reference's tree. */
+    if (!graph->simple) flags |= PLAN_REFERENCE_ORDER;
     if (graph->simple) flags |= PLAN_DEGREE_FILTER;
     if (graph->simple && envInt("GPM_SYMBREAK", 1)) flags |= PLAN_BREAK_SYMMETRY;
     gpm_plan plan;

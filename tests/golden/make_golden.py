@@ -52,6 +52,14 @@ HAND = {
     "single_vertex": "4\n1 1\n2\n3 1\n4\n\n1\n",
     # every step of the plan walks an in-edge: arcs 2->1, 3->1, 3->2, 4->3
     "reverse_plan": "5\n1 2\n2\n3\n2 1\n3\n4 2\n1\n2\n5 1\n4\n\n4\n2 1\n1\n3 2\n1\n2\n4 1\n3\n",
+    # set-symmetric multigraph (1->2 listed twice, 2->1 once), pattern arc 2->1: the level is reached over
+    # an in-edge and walks the in-list's multiplicities, not the out-list's
+    "sym_multigraph_in_edge": "2\n1 2\n2\n2\n2 1\n1\n\n2\n2 1\n1\n",
+    # twin pattern (2 and 3 have the same arcs) on a graph that lists 2->4 twice: how often a match is
+    # printed depends on which pattern arcs the plan walks
+    "multigraph_twins": "4\n1 3\n2\n3\n4\n2 2\n4\n4\n3 1\n4\n\n4\n1 3\n2\n3\n4\n2 1\n4\n3 1\n4\n",
+    # path whose vertex 1 is a leaf, data edge 1-2 listed twice one way and once the other
+    "multigraph_leaf_root": "3\n1 2\n2\n2\n2 2\n1\n3\n3 1\n2\n\n3\n1 1\n2\n2 2\n1\n3\n3 1\n2\n",
     # several blank lines between the sections, trailing text after the pattern
     "blank_runs": "3\n1 2\n2\n3\n2 1\n3\n\n\n\n2\n1 1\n2\n\nthis trailer is ignored\n7 7\n",
 }
