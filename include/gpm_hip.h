@@ -201,6 +201,22 @@ int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, void *user, 
  * line, in blocks of whole lines, in unspecified order. */
 int gpm_hip_search_text(gpm_ctx *ctx, gpm_text_sink sink, void *user, uint64_t *total);
 
+/* Count-only search that allocates nothing.  It has no counterpart in the
+ * reference; it is for callers that cannot allocate device memory while they
+ * call: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  Same result as gpm_hip_search(ctx, 1, NULL, NULL, total)
+ * on a single-GPU context whose graph and plan are installed (those calls do
+ * allocate).  All working memory -- frontiers of 65536 rows per level,
+ * candidate ranges, prefix sums, counters -- lies in one fixed 32 MiB array
+ * that each GPU holds from library load until the process ends; the call makes
+ * no hipMalloc / hipFree / hipHostMalloc and creates no events (so
+ * gpm_hip_stats reports no kernel times after it).  It runs the level-by-level
+ * and fused-intersection kernels only.  Limits: one GPU per context; longest
+ * adjacency list (either direction) at most 65472 entries, else GPM_EINVAL
+ * with a message.  Every call on one GPU shares that GPU's array: calls that
+ * overlap on one GPU (from any context or thread) race. */
+int gpm_hip_count_noalloc(gpm_ctx *ctx, uint64_t *total);
+
 int gpm_hip_stats(const gpm_ctx *ctx, gpm_stats *stats);
 
 /* Name of kernel family `kind` (GPM_KIND_*), "" when out of range. */

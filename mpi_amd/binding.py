@@ -69,7 +69,7 @@ TEXT_SINK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, cty
 HIP_SYMBOLS = ["gpm_hip_last_error", "gpm_hip_device_count", "gpm_hip_create", "gpm_hip_destroy",
                "gpm_hip_upload_graph", "gpm_hip_graph_info", "gpm_hip_set_plan", "gpm_hip_set_cursor",
                "gpm_hip_set_roots", "gpm_hip_set_chunks", "gpm_hip_search", "gpm_hip_search_text", "gpm_hip_stats",
-               "gpm_hip_kernel_name"]
+               "gpm_hip_kernel_name", "gpm_hip_count_noalloc"]
 
 _hip = None
 _host = None
@@ -97,6 +97,7 @@ def hip_lib():
         lib.gpm_hip_search_text.argtypes = [ctypes.c_void_p, TEXT_SINK, ctypes.c_void_p,
                                             ctypes.POINTER(ctypes.c_uint64)]
         lib.gpm_hip_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(gpm_stats)]
+        lib.gpm_hip_count_noalloc.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
         lib.gpm_hip_kernel_name.restype = ctypes.c_char_p
         lib.gpm_hip_kernel_name.argtypes = [ctypes.c_int]
         _hip = lib
@@ -316,6 +317,12 @@ class Matcher:
         if len(out) != total.value:
             raise GpmError(f"sink saw {len(out)} rows, search reported {total.value}")
         return out
+
+    def countNoAlloc(self) -> int:
+        """Count-only search through the entry point that allocates nothing (gpm_hip_count_noalloc)."""
+        total = ctypes.c_uint64()
+        self._check(self.lib.gpm_hip_count_noalloc(self.ctx, ctypes.byref(total)))
+        return total.value
 
     def findMatchesText(self) -> bytes:
         """Run the search in output mode with the lines formatted on the GPU; returns the

@@ -52,6 +52,38 @@ static int fail(int code, const char *fmt, ...) {
 extern "C" const char *gpm_hip_last_error(void) { return g_err.c_str(); }
 
 // ---------------------------------------------------------------------------
+// fixed device memory of the entry point that allocates nothing
+// ---------------------------------------------------------------------------
+//
+// gpm_hip_count_noalloc() keeps its frontiers, candidate ranges, prefix sums
+// and counters in this array instead of allocated buffers.  Every GPU the
+// library runs on holds its own copy until the process ends.  On the host the
+// array's name is only a handle: the address a kernel can use comes from
+// hipGetSymbolAddress, once per device, and is what every launch, memset and
+// copy below is given.
+#define NOALLOC_ROWS ((int64_t)1 << 16)      // rows per frontier level
+#define NOALLOC_BYTES ((size_t)32 << 20)     // 32 MiB per GPU
+#define NOALLOC_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char gpm_scratch[NOALLOC_BYTES];
+static unsigned char *g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+static std::mutex g_scratch_mu;
+
+// Address of this device's copy of gpm_scratch; `dev` must be the current device.
+static int scratch_address(int dev, unsigned char **out) {
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return fail(GPM_EINVAL, "device %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        unsigned char *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(gpm_scratch));
+        if (e != hipSuccess || !ptr)
+            return fail(GPM_ENODEV, "hipGetSymbolAddress(gpm_scratch) on device %d: %s", dev, hipGetErrorString(e));
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return GPM_OK;
+}
+
+// ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
 
@@ -159,6 +191,9 @@ struct DevState {
     uint64_t launches_kind[GPM_KERNEL_KINDS] = {}, bytes_kind[GPM_KERNEL_KINDS] = {};
     int rc = 0;
     std::string err;
+    // true for the view gpm_hip_count_noalloc() searches with: every buffer lies in gpm_scratch, nothing is
+    // (re)allocated and launches are not timed (events would have to be created)
+    bool fixed = false;
 };
 
 struct RowBatch {
@@ -200,6 +235,8 @@ struct gpm_ctx {
     std::atomic<bool> stop{false};
     gpm_stats stats{};
     std::vector<void *> comms;  // one RCCL communicator per GPU (several GPUs, or GPM_FORCE_RCCL=1)
+    DevState na;                      // view of devs[0] whose search buffers lie in gpm_scratch
+    unsigned char *scratch0 = nullptr;  // devs[0]'s copy of gpm_scratch
 };
 
 // ---------------------------------------------------------------------------
@@ -425,6 +462,15 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
             gpm_hip_destroy(ctx);
             return fail(GPM_ENODEV, "set-up of device %d failed: %s", d.dev, hipGetErrorString(e));
         }
+        // this device's copy of the fixed scratch array (device d.dev is current)
+        unsigned char *sp = nullptr;
+        int src = scratch_address(d.dev, &sp);
+        if (src != GPM_OK) {
+            std::string why = g_err;
+            gpm_hip_destroy(ctx);
+            return fail(src, "%s", why.c_str());
+        }
+        if (i == 0) ctx->scratch0 = sp;
     }
     ctx->chunk_roots = env_i64("GPM_CHUNK_ROOTS", 1 << 20);
     if (ctx->chunk_roots < 1) ctx->chunk_roots = 1;
@@ -1099,6 +1145,8 @@ struct SearchArgs {
     gpm_row_sink sink;
     void *user;
     gpm_text_sink text_sink;  // non-null: matches leave as text lines formatted on the GPU
+    bool fixed_memory = false;  // gpm_hip_count_noalloc: level-by-level and fused-tail kernels only (the clique and
+                                // 4-cycle paths need large allocated buffers), roots cut into equal chunks
 };
 
 static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
@@ -1174,6 +1222,7 @@ static int read_ctr(DevState &d, int slot, uint64_t *out) {
 }
 
 static int timed_begin(DevState &d, int kind, int64_t rows = 0, hipStream_t stream = nullptr, int tag = 0) {
+    if (d.fixed) return GPM_OK;
     if (d.events_used == d.events.size()) {
         EventPair ev{};
         ev.kind = kind;
@@ -1189,6 +1238,7 @@ static int timed_begin(DevState &d, int kind, int64_t rows = 0, hipStream_t stre
 }
 
 static int timed_end(DevState &d, hipStream_t stream = nullptr) {
+    if (d.fixed) return GPM_OK;
     HIP_TRY(hipEventRecord(d.events[d.events_used].b, stream ? stream : d.stream));
     d.events_used++;
     return GPM_OK;
@@ -1355,7 +1405,7 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
         return timed_end(d);
     }
     if (a.count_only && ctx->use_tail && k == P - 3 && ctx->t3.enabled && !d.no_fuse3) {
-        if (!d.over_rows) HIP_TRY(hipMalloc(&d.over_rows, 2 * (size_t)d.cap_rows * sizeof(int64_t)));
+        if (!d.over_rows) HIP_TRY(hipMalloc(&d.over_rows, 2 * (size_t)d.cap_rows * sizeof(int64_t)));  // never for a fixed view
         int64_t *over1 = d.over_rows, *over2 = d.over_rows + d.cap_rows;
         HIP_TRY(hipMemsetAsync(d.ctr + CTR_OVER, 0, 2 * sizeof(unsigned long long), s));
         // 8 lanes and sets of up to 64 per partial match; what does not fit goes to 16 lanes with sets of up
@@ -1844,9 +1894,13 @@ static int device_search(const SearchArgs &a, DevState &d) {
     gpm_ctx *ctx = a.ctx;
     const int P = ctx->pv.P;
     HIP_TRY(hipSetDevice(d.dev));
-    int rc = ensure_buffers(ctx, d, a.count_only);
-    if (rc) return rc;
+    int rc = GPM_OK;
     hipStream_t s = d.stream;
+    if (d.fixed) {  // the fixed array keeps the last call's contents: what must start at zero is cleared here
+        for (int k = 0; k + 1 < std::max(P, 2); ++k) HIP_TRY(hipMemsetAsync(d.pref[k], 0, sizeof(int64_t), s));
+    } else if ((rc = ensure_buffers(ctx, d, a.count_only))) {
+        return rc;
+    }
     HIP_TRY(hipMemsetAsync(d.ctr, 0, CTR_COUNT * sizeof(unsigned long long), s));
     d.canonical = d.alg_bytes = d.tail_bytes = d.chunks = 0;
     for (int kd = 0; kd < GPM_KERNEL_KINDS; ++kd) {
@@ -1856,10 +1910,10 @@ static int device_search(const SearchArgs &a, DevState &d) {
     d.events_used = 0;
     memset(d.rows_in, 0, sizeof d.rows_in);
     uint64_t p1_rows = 0;
-    const bool clique = a.count_only && ctx->clique_k >= 3 && ctx->use_clique;
+    const bool clique = a.count_only && ctx->clique_k >= 3 && ctx->use_clique && !a.fixed_memory;
     if (clique) HIP_TRY(hipMemsetAsync(d.clq_slots, 0, GPM_KERNEL_KINDS * CLQ_SLOTS * sizeof(unsigned long long), s));
     HIP_TRY(hipStreamSynchronize(s));  // counters are zero before any slot stream adds to them
-    const bool cyc = a.count_only && ctx->cycle4 && ctx->use_cycle4;
+    const bool cyc = a.count_only && ctx->cycle4 && ctx->use_cycle4 && !a.fixed_memory;
     if (cyc) {
         if ((rc = ensure_cycle4(ctx, d))) return rc;
         HIP_TRY(hipMemsetAsync(d.cyc_queue, 0, 1024 * sizeof(unsigned long long), s));
@@ -1870,10 +1924,20 @@ static int device_search(const SearchArgs &a, DevState &d) {
     // then add up to the wall time, which is how a kernel's own rate is measured)
     const int clq_inflight = (int)std::min<int64_t>(CLQ_INFLIGHT, std::max<int64_t>(1, env_i64("GPM_CLIQUE_INFLIGHT", CLQ_INFLIGHT)));
     const auto t_begin = std::chrono::steady_clock::now();
+    uint64_t next_fixed = 0;  // fixed-memory search: equal chunks of the root range, no chunk table
+    Chunk fixed_chunk{};
     while (!ctx->stop) {
-        const uint64_t c = claim_chunk(ctx);
-        if (c >= ctx->chunks.size()) break;
-        const Chunk &ch = ctx->chunks[(size_t)c];
+        uint64_t c;
+        if (a.fixed_memory) {
+            c = next_fixed++;
+            fixed_chunk.lo = ctx->root_lo + (int64_t)c * d.cap_rows;
+            fixed_chunk.hi = std::min(ctx->root_hi, fixed_chunk.lo + d.cap_rows);
+            if (fixed_chunk.lo >= ctx->root_hi) break;
+        } else {
+            c = claim_chunk(ctx);
+            if (c >= ctx->chunks.size()) break;
+        }
+        const Chunk &ch = a.fixed_memory ? fixed_chunk : ctx->chunks[(size_t)c];
         const int64_t lo = ch.lo, hi = ch.hi;
         d.chunks++;
         if (cyc) {
@@ -2148,6 +2212,86 @@ extern "C" int gpm_hip_search(gpm_ctx *ctx, int count_only, gpm_row_sink sink, v
 extern "C" int gpm_hip_search_text(gpm_ctx *ctx, gpm_text_sink sink, void *user, uint64_t *total) {
     if (!sink) return fail(GPM_EINVAL, "text output needs a sink");
     return search_impl(ctx, 0, nullptr, sink, user, total);
+}
+
+// Count-only search of a single-GPU context that allocates nothing: its
+// frontiers, candidate ranges, prefix sums, scan workspace and counters are
+// carved out of this GPU's copy of gpm_scratch, whose address gpm_hip_create
+// looked up.  The pinned words results are read back through were made by
+// gpm_hip_create as well.  Runs the level-by-level and fused-tail kernels;
+// every call on one GPU uses the same array, so overlapping calls would race.
+extern "C" int gpm_hip_count_noalloc(gpm_ctx *ctx, uint64_t *total) {
+    if (!ctx || !total) return fail(GPM_EINVAL, "null argument");
+    if (!ctx->have_graph || !ctx->have_plan) return fail(GPM_ESTATE, "upload a graph and set a plan first");
+    if (ctx->devs.size() != 1) return fail(GPM_EINVAL, "the no-allocation search runs on a single-GPU context");
+    if (!ctx->scratch0) return fail(GPM_ESTATE, "the fixed scratch array was not located");
+    const int64_t cap = NOALLOC_ROWS;
+    const int64_t longest = (int64_t)std::max(ctx->info.max_out_deg, ctx->info.max_in_deg);
+    if (longest + 64 > cap)
+        return fail(GPM_EINVAL,
+                    "the longest adjacency list has %lld entries; the no-allocation search takes at most %lld "
+                    "(use gpm_hip_search)", (long long)longest, (long long)(cap - 64));
+    (void)hipGetLastError();
+    const double t0 = now_seconds();
+    DevState &d0 = ctx->devs[0];
+    DevState &v = ctx->na;
+    HIP_TRY(hipSetDevice(d0.dev));
+    v.fixed = true;
+    v.dev = d0.dev;
+    v.stream = d0.stream;
+    v.n = d0.n;
+    v.gv = d0.gv;
+    v.perm = d0.perm;
+    v.ls_terms = d0.ls_terms;
+    v.ctr_host = d0.ctr_host;
+    v.i64_host = d0.i64_host;
+    v.cap_rows = cap;
+    v.cap_emit = 0;
+    // carve the array: every piece starts on a 256-byte boundary
+    unsigned char *base = ctx->scratch0;
+    size_t used = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char *p = base + used;
+        used += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    for (int k = 0; k + 1 < GPM_MAXP; ++k) {
+        v.F[k] = (int32_t *)take((size_t)cap * (size_t)(k + 1) * sizeof(int32_t));
+        v.beg[k] = (int64_t *)take((size_t)cap * sizeof(int64_t));
+        v.cnt[k] = (int64_t *)take((size_t)cap * sizeof(int64_t));
+        v.pref[k] = (int64_t *)take(((size_t)cap + 1) * sizeof(int64_t));
+        v.wsel[k] = (int8_t *)take((size_t)cap);
+    }
+    v.over_rows = (int64_t *)take(2 * (size_t)cap * sizeof(int64_t));
+    v.ctr = (unsigned long long *)take(CTR_COUNT * sizeof(unsigned long long));
+    v.i64_dev = (int64_t *)take(4 * sizeof(int64_t));
+    if (used > NOALLOC_BYTES) return fail(GPM_ERUNTIME, "fixed scratch layout needs %zu bytes", used);
+    v.scan_tmp = take(0);
+    size_t scan_bytes = 0;  // a size query: allocates nothing
+    HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, v.cnt[0], v.pref[0] + 1, (size_t)cap, rocprim::plus<int64_t>(),
+                                    v.stream));
+    v.scan_tmp_bytes = scan_bytes ? scan_bytes : 8;
+    if (used + v.scan_tmp_bytes > NOALLOC_BYTES)
+        return fail(GPM_ERUNTIME, "fixed scratch layout needs %zu bytes", used + v.scan_tmp_bytes);
+    ctx->stop = false;
+    SearchArgs a{ctx, true, true, nullptr, nullptr, nullptr, true};
+    int rc = device_search(a, v);
+    if (rc != GPM_OK) {
+        (void)hipStreamSynchronize(v.stream);
+        return rc;
+    }
+    gpm_stats &st = ctx->stats;
+    memset(&st, 0, sizeof st);
+    st.canonical = v.canonical;
+    st.matches = v.canonical * ctx->plan.n_aut;
+    st.alg_bytes = v.alg_bytes;
+    st.tail_alg_bytes = v.tail_bytes;
+    for (int k = 0; k < GPM_MAXP; ++k) st.rows_in[k] = v.rows_in[k];
+    for (int kd = 0; kd < GPM_KERNEL_KINDS; ++kd) st.kernel_alg_bytes[kd] = v.bytes_kind[kd];
+    st.chunks[0] = v.chunks;
+    st.ms_total = 1e3 * (now_seconds() - t0);
+    *total = st.matches;
+    return GPM_OK;
 }
 
 extern "C" const char *gpm_hip_kernel_name(int kind) {
