@@ -184,6 +184,15 @@ int gpm_hip_set_cursor(gpm_ctx *ctx, volatile uint64_t *cursor);
  * they build the same chunk table. */
 int gpm_hip_set_chunks(gpm_ctx *ctx, int64_t n_chunks);
 
+/* Merge-model byte accounting of the clique kernels (gpm_stats.kernel_alg_bytes
+ * of GPM_KIND_CLIQUE / CLQ_BUILD / CLQ_COUNT) on or off; default on, or the
+ * value of GPM_ACCOUNTING.  The sums cost an add per adjacent pair inside the
+ * kernels and two list-length lookups per universe entry, so a timed run
+ * switches them off and takes the bytes -- a property of the work, not of the
+ * run -- from a search with accounting on.  Results are the same either way;
+ * every other kernel family always counts its bytes. */
+int gpm_hip_set_accounting(gpm_ctx *ctx, int on);
+
 /* Restrict roots to [lo, hi) of the library's root order (0 <= lo <= hi <= n);
  * default is all n.  Used for sharding tests. */
 int gpm_hip_set_roots(gpm_ctx *ctx, int64_t lo, int64_t hi);

@@ -69,7 +69,7 @@ TEXT_SINK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, cty
 HIP_SYMBOLS = ["gpm_hip_last_error", "gpm_hip_device_count", "gpm_hip_create", "gpm_hip_destroy",
                "gpm_hip_upload_graph", "gpm_hip_graph_info", "gpm_hip_set_plan", "gpm_hip_set_cursor",
                "gpm_hip_set_roots", "gpm_hip_set_chunks", "gpm_hip_search", "gpm_hip_search_text", "gpm_hip_stats",
-               "gpm_hip_kernel_name", "gpm_hip_count_noalloc"]
+               "gpm_hip_kernel_name", "gpm_hip_count_noalloc", "gpm_hip_set_accounting"]
 
 _hip = None
 _host = None
@@ -92,6 +92,7 @@ def hip_lib():
         lib.gpm_hip_set_cursor.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.gpm_hip_set_roots.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
         lib.gpm_hip_set_chunks.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        lib.gpm_hip_set_accounting.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.gpm_hip_search.argtypes = [ctypes.c_void_p, ctypes.c_int, ROW_SINK, ctypes.c_void_p,
                                        ctypes.POINTER(ctypes.c_uint64)]
         lib.gpm_hip_search_text.argtypes = [ctypes.c_void_p, TEXT_SINK, ctypes.c_void_p,
@@ -292,6 +293,9 @@ class Matcher:
 
     def set_chunks(self, n_chunks):
         self._check(self.lib.gpm_hip_set_chunks(self.ctx, n_chunks))
+
+    def set_accounting(self, on: bool):
+        self._check(self.lib.gpm_hip_set_accounting(self.ctx, 1 if on else 0))
 
     def set_cursor(self, address):
         self._check(self.lib.gpm_hip_set_cursor(self.ctx, address))

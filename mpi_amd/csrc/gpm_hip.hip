@@ -170,6 +170,11 @@ struct DevState {
     ChunkSlot slots[CLQ_INFLIGHT];
     int64_t clq_stride = 0;
     int clq_scratch_blocks = 0;
+    int clq_probe_bias = 0;    // GPM_CLIQUE_PROBE_BIAS, read once per context
+    bool count4_wide = true;   // GPM_COUNT4_WAVES >= 16
+    int clq_lists_max_class = 2;  // GPM_CLQ_LISTS_MAX_CLASS: size classes up to this one build their rows from the
+                                  // adjacency lists, larger ones from hub-matrix gathers (1 = gathers only)
+    int clq_build_rb = 0;         // GPM_CLQ_BUILD_RB: workgroups per root of that kernel (0 = by size class)
     unsigned long long *clq_slots = nullptr;  // [0,CLQ_SLOTS) matches, [CLQ_SLOTS,2*CLQ_SLOTS) bytes
     // 4-cycle path: two-path count of every root, counter arrays (cyc_blocks of them for the workgroups of
     // the light kernel, then CYC_HEAVY_GROUPS groups of cyc_batch for heavy roots), root queues of the light
@@ -217,6 +222,7 @@ struct gpm_ctx {
     bool use_clique = true;
     bool cycle4 = false;  // the plan is the 4-cycle with all 8 automorphisms folded
     bool use_cycle4 = true;
+    bool accounting = true;  // sum merge-model bytes in the clique kernels (gpm_hip_set_accounting)
     int64_t cyc_heavy_thr = 0;             // two-paths from which a root is cut into spans (k_cycle4_heavy)
     std::vector<int64_t> cyc_heavy_roots;  // root indices at or above the threshold, ascending
     std::vector<int64_t> cyc_heavy_paths;  // their two-path counts
@@ -479,6 +485,13 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->use_clique = env_i64("GPM_NO_CLIQUE", 0) == 0;
     ctx->use_cycle4 = env_i64("GPM_NO_CYCLE4", 0) == 0;
     ctx->cyc_heavy_thr = std::max<int64_t>(1, env_i64("GPM_CYCLE4_HEAVY", (int64_t)1 << 16));
+    ctx->accounting = env_i64("GPM_ACCOUNTING", 1) != 0;
+    for (auto &d : ctx->devs) {
+        d.clq_probe_bias = (int)env_i64("GPM_CLIQUE_PROBE_BIAS", 0);
+        d.count4_wide = env_i64("GPM_COUNT4_WAVES", 16) >= 16;
+        d.clq_lists_max_class = (int)env_i64("GPM_CLQ_LISTS_MAX_CLASS", 2);
+        d.clq_build_rb = (int)env_i64("GPM_CLQ_BUILD_RB", 0);
+    }
     // GPM_NO_RCCL=1: per-GPU counts are summed on the host only (also lets two workers share one GPU in tests)
     if ((ngpus > 1 && env_i64("GPM_NO_RCCL", 0) == 0) || env_i64("GPM_FORCE_RCCL", 0)) {
         if (!rccl().ok()) {
@@ -1126,6 +1139,12 @@ extern "C" int gpm_hip_set_roots(gpm_ctx *ctx, int64_t lo, int64_t hi) {
     return GPM_OK;
 }
 
+extern "C" int gpm_hip_set_accounting(gpm_ctx *ctx, int on) {
+    if (!ctx) return fail(GPM_EINVAL, "null context");
+    ctx->accounting = on != 0;
+    return GPM_OK;
+}
+
 extern "C" int gpm_hip_set_chunks(gpm_ctx *ctx, int64_t n_chunks) {
     if (!ctx) return fail(GPM_EINVAL, "null context");
     if (n_chunks < 0) return fail(GPM_EINVAL, "chunk count must not be negative");
@@ -1597,14 +1616,20 @@ static size_t clq_lds_bytes(int K, int block, int dcap, bool rows_in_lds) {
     return words * sizeof(uint32_t);
 }
 
-// Classes 2..4 of a chunk through the build/count kernel pair (K = 3: the
-// build kernel counts the triangles itself; K = 4: tiled count).
-template <int K>
-static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CLASSES], int bias) {
+// Classes 2..5 of a chunk through the build/count kernel pair (K = 3: the
+// build kernel counts the triangles itself; K = 4: tiled count).  all_hub: every
+// root of the chunk (and so every vertex of its universes) lies in the hub
+// matrix; stats: sum the merge-model bytes as well.
+template <int K, bool STATS, bool ALL_HUB>
+static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CLASSES], int bias, int64_t chunk_hi) {
     static_assert(K == 3 || K == 4, "build/count pair exists for triangles and 4-cliques");
     hipStream_t s = sl.stream;
     unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + (size_t)GPM_KIND_CLQ_BUILD * CLQ_SLOTS;
     unsigned long long *byt3 = d.clq_slots + (size_t)GPM_KIND_CLQ_COUNT * CLQ_SLOTS;  // level 3, done by the count kernel
+    // universes of this chunk lie above its lowest root, vertex n - chunk_hi: the id range an LDS bitmap
+    // of a universe has to cover (k_clq_build_lists), in words rounded up to a multiple of 1024
+    const int32_t base_id = (int32_t)std::max<int64_t>(0, (int64_t)d.n - chunk_hi);
+    const int bm_words = (int)((((int64_t)d.n - base_id + 31) / 32 + 1023) / 1024 * 1024);
     const int dcaps[4] = {512, 1024, 2048, 4096};
     const int64_t strides[4] = {512 * 16, 1024 * 32, (1024 + 2048) * 32, (1024 + 2048 + 3072 + 4096) * 32};
     int rc;
@@ -1614,22 +1639,32 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CL
         const int64_t stride = strides[c - 2];
         const int64_t batch = (int64_t)(CLQ_ROWS_WORDS / (size_t)stride);
         const int32_t *list = sl.lists + (int64_t)c * d.clq_stride;
-        const size_t lds_build = ((size_t)4 * dcap + 4 * 128) * sizeof(uint32_t);
+        const size_t lds_build = ((size_t)(ALL_HUB && !STATS ? 1 : 4) * dcap + 4 * 128) * sizeof(uint32_t);
         // 16 waves hide the LDS latency of the big tiles better than 8; the J lists of 16 waves and a
         // 128 KiB tile fill the 160 KiB of LDS exactly
-        const bool wide = dcap > 512 && env_i64("GPM_COUNT4_WAVES", 16) >= 16;
+        const bool wide = dcap > 512 && d.count4_wide;
         const int nw = wide ? 16 : 8, seg = wide ? 2 : 4;
         const size_t lds_count = ((size_t)nw * 512 + (size_t)std::min(dcap, 1024) * (std::min(dcap, 1024) / 32)) *
                                  sizeof(uint32_t);
         const int tcap = dcap > 1024 ? dcap / 1024 : 1, phases = tcap * (tcap + 1) / 2;
         for (int64_t b0 = 0; b0 < (int64_t)n[c]; b0 += batch) {
             const int64_t nb = std::min<int64_t>(batch, (int64_t)n[c] - b0);
-            if (lds_build > 48 * 1024)
-                HIP_TRY(hipFuncSetAttribute((const void *)k_clq_build<K>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds_build));
             if ((rc = timed_begin(d, GPM_KIND_CLQ_BUILD, nb, s, c))) return rc;
-            k_clq_build<K><<<(unsigned)(nb * (dcap / BIG_ROWS_PER_WG)), 256, lds_build, s>>>(
-                d.gv, list + b0, nb, dcap, bias, sl.rows, stride, cnt, byt, byt3);
+            if (ALL_HUB && !STATS && c <= d.clq_lists_max_class && bm_words <= CLQ_BM_MAX_WORDS) {
+                // rows from the adjacency lists, tested against a bitmap of the universe in LDS
+                const int RB = d.clq_build_rb > 0 ? d.clq_build_rb : (c == 2 ? 1 : c == 3 ? 2 : c == 4 ? 4 : 8);
+                const size_t lds_lists = ((size_t)bm_words + bm_words / 2 + dcap + 4 * 128) * sizeof(uint32_t);
+                HIP_TRY(hipFuncSetAttribute((const void *)k_clq_build_lists<K>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists));
+                k_clq_build_lists<K><<<(unsigned)(nb * RB), 256, lds_lists, s>>>(d.gv, list + b0, nb, dcap, RB, base_id,
+                                                                              bm_words, sl.rows, stride, cnt);
+            } else {
+                if (lds_build > 48 * 1024)
+                    HIP_TRY(hipFuncSetAttribute((const void *)k_clq_build<K, STATS, ALL_HUB>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
+                k_clq_build<K, STATS, ALL_HUB><<<(unsigned)(nb * (dcap / BIG_ROWS_PER_WG)), 256, lds_build, s>>>(
+                    d.gv, list + b0, nb, dcap, bias, sl.rows, stride, cnt, byt, byt3);
+            }
             HIP_TRY(hipGetLastError());
             if ((rc = timed_end(d, s))) return rc;
             if (K == 4) {
@@ -1653,21 +1688,25 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CL
     return GPM_OK;
 }
 
-template <int K>
-static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CLASSES]) {
+template <int K, bool STATS>
+static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CLASSES], bool all_hub, int64_t chunk_hi) {
     hipStream_t s = sl.stream;
     unsigned long long *cnt = d.clq_slots, *byt = d.clq_slots + (size_t)GPM_KIND_CLIQUE * CLQ_SLOTS;
     const int32_t *l = sl.lists;
     const int64_t st = d.clq_stride;
-    const int bias = (int)env_i64("GPM_CLIQUE_PROBE_BIAS", 0);
+    const int bias = d.clq_probe_bias;
     int rc;
     if constexpr (K == 3 || K == 4) {
-        if ((rc = clique_launch_big<K>(d, sl, n, bias))) return rc;
+        // the gather-only build kernel needs every universe inside the hub matrix and no list-walk bias
+        const bool fast = all_hub && bias == 0;
+        rc = fast ? clique_launch_big<K, STATS, true>(d, sl, n, bias, chunk_hi)
+                  : clique_launch_big<K, STATS, false>(d, sl, n, bias, chunk_hi);
+        if (rc) return rc;
     } else {
         if (n[4]) {  // rows in global scratch, persistent workgroups
             unsigned blocks = (unsigned)std::min<uint64_t>(n[4], (uint64_t)d.clq_scratch_blocks);
             if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[4], s, 4))) return rc;
-            k_clique<K, 256, false><<<blocks, 256, clq_lds_bytes(K, 256, CLQ_MAX_D, false), s>>>(
+            k_clique<K, 256, false, STATS><<<blocks, 256, clq_lds_bytes(K, 256, CLQ_MAX_D, false), s>>>(
                 d.gv, l + 4 * st, (int64_t)n[4], CLQ_MAX_D, bias, sl.scratch, cnt, byt);
             HIP_TRY(hipGetLastError());
             if ((rc = timed_end(d, s))) return rc;
@@ -1675,10 +1714,10 @@ static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CLASSE
         for (int c = 3; c >= 2; --c) {
             if (!n[c]) continue;
             const size_t lds = clq_lds_bytes(K, 512, 1024, true);
-            HIP_TRY(hipFuncSetAttribute((const void *)k_clique<K, 512, true>,
+            HIP_TRY(hipFuncSetAttribute((const void *)k_clique<K, 512, true, STATS>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[c], s, c))) return rc;
-            k_clique<K, 512, true><<<(unsigned)n[c], 512, lds, s>>>(d.gv, l + c * st, (int64_t)n[c], 1024, bias,
+            k_clique<K, 512, true, STATS><<<(unsigned)n[c], 512, lds, s>>>(d.gv, l + c * st, (int64_t)n[c], 1024, bias,
                                                                     nullptr, cnt, byt);
             HIP_TRY(hipGetLastError());
             if ((rc = timed_end(d, s))) return rc;
@@ -1686,14 +1725,14 @@ static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CLASSE
     }
     if (n[1]) {
         if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[1], s, 1))) return rc;
-        k_clique<K, 256, true><<<(unsigned)n[1], 256, clq_lds_bytes(K, 256, 256, true), s>>>(
+        k_clique<K, 256, true, STATS><<<(unsigned)n[1], 256, clq_lds_bytes(K, 256, 256, true), s>>>(
             d.gv, l + st, (int64_t)n[1], 256, bias, nullptr, cnt, byt);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d, s))) return rc;
     }
     if (n[0]) {
         if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[0], s, 0))) return rc;
-        k_clique<K, 64, true><<<(unsigned)n[0], 64, clq_lds_bytes(K, 64, 64, true), s>>>(d.gv, l, (int64_t)n[0], 64, bias,
+        k_clique<K, 64, true, STATS><<<(unsigned)n[0], 64, clq_lds_bytes(K, 64, 64, true), s>>>(d.gv, l, (int64_t)n[0], 64, bias,
                                                                                      nullptr, cnt, byt);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d, s))) return rc;
@@ -1709,6 +1748,14 @@ static int clique_max_d(int K) {
     return (int)std::min<int64_t>(cap, std::max<int64_t>(0, env_i64("GPM_CLIQUE_MAX_D", cap)));
 }
 
+// Largest universe of the in-LDS kernel's classes 0 and 1.  GPM_CLIQUE_SMALL_MAX lowers it for triangles and
+// 4-cliques (which have the build / count pair for everything larger), so that tests on small graphs run
+// those kernels.
+static int clique_small_max(int K) {
+    if (K > 4) return 256;
+    return (int)std::min<int64_t>(256, std::max<int64_t>(4, env_i64("GPM_CLIQUE_SMALL_MAX", 256)));
+}
+
 // One chunk of roots through the bitmap kernel, enqueued on the slot's stream
 // without any host round trip: the per-class root counts come from the chunk
 // table.  Roots whose N+ exceeds the kernel's universe (class 4) go through
@@ -1717,20 +1764,22 @@ static int clique_chunk(const SearchArgs &a, DevState &d, ChunkSlot &sl, const C
     gpm_ctx *ctx = a.ctx;
     hipStream_t s = sl.stream;
     HIP_TRY(hipMemsetAsync(sl.counts, 0, 8 * sizeof(unsigned long long), s));
-    k_clique_bin<<<grid_for(ch.hi - ch.lo), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx->clique_k), ch.lo, ch.hi, sl.lists,
+    k_clique_bin<<<grid_for(ch.hi - ch.lo), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx->clique_k), clique_small_max(ctx->clique_k), ch.lo, ch.hi, sl.lists,
                                                          d.clq_stride, sl.counts);
     HIP_TRY(hipGetLastError());
     d.rows_in[0] += (uint64_t)ch.n[0] + ch.n[1] + ch.n[2] + ch.n[3] + ch.n[4] + ch.n[5];
     int rc = GPM_OK;
+    // roots run from vertex n-1-lo down to n-hi; universes only hold higher vertices
+    const bool all_hub = d.gv.hub != nullptr && (int64_t)ctx->info.n - ch.hi >= (int64_t)d.gv.hub_base;
     switch (ctx->clique_k) {
-        case 3: rc = clique_launch<3>(d, sl, ch.n); break;
-        case 4: rc = clique_launch<4>(d, sl, ch.n); break;
-        case 5: rc = clique_launch<5>(d, sl, ch.n); break;
-        case 6: rc = clique_launch<6>(d, sl, ch.n); break;
-        case 7: rc = clique_launch<7>(d, sl, ch.n); break;
-        case 8: rc = clique_launch<8>(d, sl, ch.n); break;
-        case 9: rc = clique_launch<9>(d, sl, ch.n); break;
-        case 10: rc = clique_launch<10>(d, sl, ch.n); break;
+        case 3: rc = ctx->accounting ? clique_launch<3, true>(d, sl, ch.n, all_hub, ch.hi) : clique_launch<3, false>(d, sl, ch.n, all_hub, ch.hi); break;
+        case 4: rc = ctx->accounting ? clique_launch<4, true>(d, sl, ch.n, all_hub, ch.hi) : clique_launch<4, false>(d, sl, ch.n, all_hub, ch.hi); break;
+        case 5: rc = ctx->accounting ? clique_launch<5, true>(d, sl, ch.n, all_hub, ch.hi) : clique_launch<5, false>(d, sl, ch.n, all_hub, ch.hi); break;
+        case 6: rc = ctx->accounting ? clique_launch<6, true>(d, sl, ch.n, all_hub, ch.hi) : clique_launch<6, false>(d, sl, ch.n, all_hub, ch.hi); break;
+        case 7: rc = ctx->accounting ? clique_launch<7, true>(d, sl, ch.n, all_hub, ch.hi) : clique_launch<7, false>(d, sl, ch.n, all_hub, ch.hi); break;
+        case 8: rc = ctx->accounting ? clique_launch<8, true>(d, sl, ch.n, all_hub, ch.hi) : clique_launch<8, false>(d, sl, ch.n, all_hub, ch.hi); break;
+        case 9: rc = ctx->accounting ? clique_launch<9, true>(d, sl, ch.n, all_hub, ch.hi) : clique_launch<9, false>(d, sl, ch.n, all_hub, ch.hi); break;
+        case 10: rc = ctx->accounting ? clique_launch<10, true>(d, sl, ch.n, all_hub, ch.hi) : clique_launch<10, false>(d, sl, ch.n, all_hub, ch.hi); break;
         default: return fail(GPM_ERUNTIME, "clique size %d not supported", ctx->clique_k);
     }
     if (rc) return rc;
@@ -1865,7 +1914,7 @@ static int prepare_chunks(gpm_ctx *ctx) {
         HIP_TRY(hipMalloc(&table, (size_t)nch * CLQ_CLASSES * sizeof(unsigned int)));
         HIP_TRY(hipMemcpyAsync(dbounds, bounds.data(), (size_t)nch * sizeof(int64_t), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(table, 0, (size_t)nch * CLQ_CLASSES * sizeof(unsigned int), s));
-        k_chunk_classes<<<grid_for(nroots), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx->clique_k), lo, hi, dbounds, nch,
+        k_chunk_classes<<<grid_for(nroots), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx->clique_k), clique_small_max(ctx->clique_k), lo, hi, dbounds, nch,
                                                          table);
         std::vector<unsigned int> htable((size_t)nch * CLQ_CLASSES);
         HIP_TRY(hipMemcpyAsync(htable.data(), table, htable.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, s));

@@ -942,15 +942,18 @@ __global__ void k_hub_fill(GraphView g, uint32_t *bits) {
 #define CLQ_SLOTS 1024                 // result counters are spread over this many slots
 #define CLQ_CLASSES 7
 
-__device__ __forceinline__ int clq_class(int64_t d, int max_d) {
-    return d > max_d ? CLQ_CLASSES - 1 : d <= 64 ? 0 : d <= 256 ? 1 : d <= 512 ? 2 : d <= 1024 ? 3 : d <= 2048 ? 4 : 5;
+// small_max: largest universe of the kernels that keep their rows in LDS (256; tests lower it to send
+// small universes through the build / count kernel pair).
+__device__ __forceinline__ int clq_class(int64_t d, int max_d, int small_max) {
+    return d > max_d ? CLQ_CLASSES - 1
+         : d <= min(64, small_max) ? 0 : d <= small_max ? 1 : d <= 512 ? 2 : d <= 1024 ? 3 : d <= 2048 ? 4 : 5;
 }
 
 // Sort roots of a chunk into size classes by d = |N+(root)|; each class is a
 // compacted list (ballot + prefix popcount, one atomic per wave and class).
 //   class 0: K-1 <= d <= 64   1: d <= 256   2: d <= 512   3: d <= 1024
 //   4: d <= 2048   5: d <= 4096 (classes 4, 5 only up to max_d)   6: larger (generic path)
-__global__ void k_clique_bin(GraphView g, int K, int max_d, int64_t lo, int64_t hi, int32_t *lists,
+__global__ void k_clique_bin(GraphView g, int K, int max_d, int small_max, int64_t lo, int64_t hi, int32_t *lists,
                              int64_t list_stride, unsigned long long *counts) {
     int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int cls = -1;
@@ -958,7 +961,7 @@ __global__ void k_clique_bin(GraphView g, int K, int max_d, int64_t lo, int64_t 
     if (i < hi) {
         v = (int32_t)(g.n - 1 - i);
         int64_t d = g.off[0][v + 1] - g.mid[0][v];
-        if (d >= K - 1) cls = clq_class(d, max_d);
+        if (d >= K - 1) cls = clq_class(d, max_d, small_max);
     }
     int lane = lane_id();
     for (int c = 0; c < CLQ_CLASSES; ++c) {
@@ -984,14 +987,14 @@ __global__ void k_root_cost(GraphView g, int oriented, int min_d, int64_t lo, in
 }
 
 // Size-class histogram of the roots of every chunk (the classes of k_clique_bin).
-__global__ void k_chunk_classes(GraphView g, int K, int max_d, int64_t lo, int64_t hi, const int64_t *bounds,
+__global__ void k_chunk_classes(GraphView g, int K, int max_d, int small_max, int64_t lo, int64_t hi, const int64_t *bounds,
                                 int nchunks, unsigned int *table) {
     int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hi) return;
     int32_t v = (int32_t)(g.n - 1 - i);
     int64_t d = g.off[0][v + 1] - g.mid[0][v];
     if (d < K - 1) return;
-    int cls = clq_class(d, max_d);
+    int cls = clq_class(d, max_d, small_max);
     int a = 0, b = nchunks;  // last chunk whose first root is <= i
     while (b - a > 1) {
         int m = (a + b) >> 1;
@@ -1141,7 +1144,7 @@ __device__ __forceinline__ uint64_t clq_count(u32x4 C, const uint32_t *c_words, 
 // `work` holds the hash of U while the rows are built and afterwards, per
 // wave, the expanded list J and the nested candidate sets.  With !IN_LDS the
 // rows live in this workgroup's slab of `scratch`.
-template <int K, int BLOCK, bool IN_LDS>
+template <int K, int BLOCK, bool IN_LDS, bool STATS>
 __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
                                                   int probe_bias, uint32_t *scratch,
                                                   unsigned long long *n_matches, unsigned long long *alg_bytes) {
@@ -1179,13 +1182,19 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
         while ((1 << hbits) < 2 * d) ++hbits;
         const uint32_t hmask = (1u << hbits) - 1;
         const int hshift = 32 - hbits;
-        for (int i = tid; i <= (int)hmask; i += BLOCK) htab[i] = 0;
-        __syncthreads();
+        // Lists ascend, so a universe whose first vertex is a hub holds hubs only: every row is then
+        // gathered from the hub matrix and neither the hash of U nor the list lengths are needed.
+        const bool hubs_only = probe_bias == 0 && d > 0 && adj[ub] >= g.hub_base;
+        const bool need_dp = STATS || probe_bias != 0;
+        if (!hubs_only) {
+            for (int i = tid; i <= (int)hmask; i += BLOCK) htab[i] = 0;
+            __syncthreads();
+        }
         for (int i = tid; i < d; i += BLOCK) {
             int32_t v = adj[ub + i];
             U[i] = v;
-            Dp[i] = (uint32_t)(off[v + 1] - mid[v]);
-            clq_hash_insert(htab, hmask, hshift, v, i);
+            if (need_dp) Dp[i] = (uint32_t)(off[v + 1] - mid[v]);
+            if (!hubs_only) clq_hash_insert(htab, hmask, hshift, v, i);
         }
         __syncthreads();
 
@@ -1194,10 +1203,11 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
         for (int i = wave; i < d; i += NW) {
             const int32_t v = U[i];
             uint32_t *row = rows + (size_t)i * Wp;
-            const uint64_t per_arc = 12ull + 4ull * ((uint64_t)d + Dp[i]);
+            const uint64_t per_arc = STATS ? 12ull + 4ull * ((uint64_t)d + Dp[i]) : 0ull;
             // a hub's row is gathered from the hub matrix when its list is long
             // next to the number of positions to test (probe_bias/16 is the ratio)
-            if (v >= g.hub_base && (int64_t)Dp[i] * 16 >= (int64_t)probe_bias * (int64_t)(d - 1 - i)) {
+            if (v >= g.hub_base &&
+                (probe_bias == 0 || (int64_t)Dp[i] * 16 >= (int64_t)probe_bias * (int64_t)(d - 1 - i))) {
                 const uint32_t *hrow = g.hub + (size_t)(v - g.hub_base) * (size_t)g.hub_wpr;
                 // 256 positions per trip: four independent gathers in flight (Wp*32 is a multiple of 128)
                 for (int j0 = 0; j0 < Wp * 32; j0 += CLQ_GATHERS * GPM_WAVE) {
@@ -1222,7 +1232,7 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
                         if (jb >= Wp * 32) break;
                         const bool bit = live[k] && ((word[k] >> sh[k]) & 1u);
                         unsigned long long mask = __ballot(bit);
-                        if (bit) arcs_bytes += per_arc + 4ull * Dp[jb + lane];
+                        if (STATS && bit) arcs_bytes += per_arc + 4ull * Dp[jb + lane];
                         if (lane == 0) {
                             row[jb >> 5] = (uint32_t)mask;
                             row[(jb >> 5) + 1] = (uint32_t)(mask >> 32);
@@ -1247,7 +1257,7 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
                         int j = clq_hash_find(htab, hmask, hshift, U, w[k]);
                         if (j >= 0) {
                             atomicOr(row + (j >> 5), 1u << (j & 31));
-                            arcs_bytes += per_arc + 4ull * Dp[j];
+                            if (STATS) arcs_bytes += per_arc + 4ull * Dp[j];
                         }
                     }
                 }
@@ -1274,11 +1284,13 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
         //   (root,i) -> level 2    : 4*2 + 4*(d + Dp[i])                  for every i
         //   (root,i,j) -> level 3  : 4*3 + 4*(d + Dp[i] + Dp[j])         for every arc i->j (K >= 4)
         //   deeper internal nodes (K >= 5) at 4*4 + 4*d each: a lower bound
-        uint64_t b = K >= 4 ? arcs_bytes : 0;
-        for (int i = tid; i < d; i += BLOCK) b += 8ull + 4ull * ((uint64_t)d + Dp[i]);
-        if (tid == 0) b += 4ull + 4ull * (uint64_t)d;
-        if (K >= 5 && lane == 0) b += nodes * (16ull + 4ull * (uint64_t)d);
-        bytes += b;
+        if (STATS) {
+            uint64_t b = K >= 4 ? arcs_bytes : 0;
+            for (int i = tid; i < d; i += BLOCK) b += 8ull + 4ull * ((uint64_t)d + Dp[i]);
+            if (tid == 0) b += 4ull + 4ull * (uint64_t)d;
+            if (K >= 5 && lane == 0) b += nodes * (16ull + 4ull * (uint64_t)d);
+            bytes += b;
+        }
         __syncthreads();
     }
     total = wave_sum_u64(total);
@@ -1330,9 +1342,18 @@ __device__ __forceinline__ int64_t big_off(int t) { return (int64_t)32768 * (t *
 #define BIG_ROWS_PER_WG 64
 
 // grid = nroots * (dcap / 64) workgroups of 256 threads; workgroup (ri, rb)
-// builds rows [64*rb, 64*rb + 64) of root ri.  LDS (words): U[dcap] | Dp[dcap]
-// | hash[2*dcap] | stage[4][128].  K == 3 only counts the bits (triangles).
-template <int K>
+// builds rows [64*rb, 64*rb + 64) of root ri.  K == 3 only counts the bits
+// (triangles).
+//
+// ALL_HUB: every vertex of every universe of the launch is a hub (the host
+// checks the lowest root of the chunk), so every row is gathered from the hub
+// matrix and nothing but U is staged: LDS (words) U[dcap] | stage[4][128].
+// Otherwise rows of non-hubs are hashed list walks: U[dcap] | Dp[dcap] |
+// hash[2*dcap] | stage[4][128].
+// STATS: also sum the merge-model bytes of the levels this kernel and the count
+// kernel do (needs Dp, and an add per set bit in the inner loops); off in timed
+// runs, on in the accounting search.
+template <int K, bool STATS, bool ALL_HUB>
 __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
                                                    int probe_bias, uint32_t *rows_buf, int64_t stride_words,
                                                    unsigned long long *n_matches, unsigned long long *alg_bytes,
@@ -1349,24 +1370,29 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
     const int64_t ub = mid[u];
     const int d = (int)(off[u + 1] - ub);
     if (i0 >= d) return;
+    constexpr bool NEED_DP = STATS || !ALL_HUB;  // Dp also steers the gather / list-walk choice of a hub row
     int32_t *U = (int32_t *)smem;
     uint32_t *Dp = smem + dcap;
     uint32_t *htab = smem + 2 * dcap;
-    uint32_t *stage = smem + 4 * dcap + wave * 128;
+    uint32_t *stage = smem + (ALL_HUB && !STATS ? dcap : 4 * dcap) + wave * 128;
     const int T = big_tiles(d);
     uint32_t *region = rows_buf + ri * stride_words;
 
-    int hbits = 1;
-    while ((1 << hbits) < 2 * d) ++hbits;
-    const uint32_t hmask = (1u << hbits) - 1;
-    const int hshift = 32 - hbits;
-    for (int i = tid; i <= (int)hmask; i += 256) htab[i] = 0;
-    __syncthreads();
+    uint32_t hmask = 0;
+    int hshift = 0;
+    if (!ALL_HUB) {
+        int hbits = 1;
+        while ((1 << hbits) < 2 * d) ++hbits;
+        hmask = (1u << hbits) - 1;
+        hshift = 32 - hbits;
+        for (int i = tid; i <= (int)hmask; i += 256) htab[i] = 0;
+        __syncthreads();
+    }
     for (int i = tid; i < d; i += 256) {
         int32_t v = adj[ub + i];
         U[i] = v;
-        Dp[i] = (uint32_t)(off[v + 1] - mid[v]);
-        clq_hash_insert(htab, hmask, hshift, v, i);
+        if (NEED_DP) Dp[i] = (uint32_t)(off[v + 1] - mid[v]);
+        if (!ALL_HUB) clq_hash_insert(htab, hmask, hshift, v, i);
     }
     __syncthreads();
 
@@ -1375,10 +1401,17 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
     const int i_end = min(d, i0 + BIG_ROWS_PER_WG);
     for (int i = i0 + wave; i < i_end; i += 4) {
         const int32_t v = U[i];
-        const uint64_t per_arc = 12ull + 4ull * ((uint64_t)d + Dp[i]);
-        if (v >= g.hub_base && (int64_t)Dp[i] * 16 >= (int64_t)probe_bias * (int64_t)(d - 1 - i)) {
+        const uint64_t per_arc = STATS ? 12ull + 4ull * ((uint64_t)d + Dp[i]) : 0ull;
+        bool gather = ALL_HUB;
+        if (!ALL_HUB)
+            gather = v >= g.hub_base && (int64_t)Dp[i] * 16 >= (int64_t)probe_bias * (int64_t)(d - 1 - i);
+        if (gather) {
             const uint32_t *hrow = g.hub + (size_t)(v - g.hub_base) * (size_t)g.hub_wpr;
-            for (int j0 = 0; j0 < Wall * 32; j0 += CLQ_GATHERS * GPM_WAVE) {
+            // positions up to i hold no bits: whole trips below i are zeros, no loads
+            const int jfirst = ((i + 1) / (CLQ_GATHERS * GPM_WAVE)) * (CLQ_GATHERS * GPM_WAVE);
+            if (K != 3)
+                for (int w = lane; w < (jfirst >> 5); w += GPM_WAVE) stage[w] = 0;
+            for (int j0 = jfirst; j0 < Wall * 32; j0 += CLQ_GATHERS * GPM_WAVE) {
                 uint32_t word[CLQ_GATHERS], sh[CLQ_GATHERS];
                 bool live[CLQ_GATHERS];
 #pragma unroll
@@ -1399,15 +1432,15 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
                     if (jb >= Wall * 32) break;
                     const bool bit = live[k] && ((word[k] >> sh[k]) & 1u);
                     unsigned long long mask = __ballot(bit);
-                    if (K >= 4 && bit) bytes3 += per_arc + 4ull * Dp[jb + lane];
+                    if (STATS && K >= 4 && bit) bytes3 += per_arc + 4ull * Dp[jb + lane];
                     if (K == 3) tri += bit;
-                    if (lane == 0) {
+                    if (K != 3 && lane == 0) {
                         stage[jb >> 5] = (uint32_t)mask;
                         stage[(jb >> 5) + 1] = (uint32_t)(mask >> 32);
                     }
                 }
             }
-        } else {
+        } else if (!ALL_HUB) {
             stage[lane] = 0;
             stage[GPM_WAVE + lane] = 0;
             wave_lds_sync();
@@ -1425,7 +1458,7 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
                     int j = clq_hash_find(htab, hmask, hshift, U, w[k]);
                     if (j >= 0) {
                         atomicOr(stage + (j >> 5), 1u << (j & 31));
-                        if (K >= 4) bytes3 += per_arc + 4ull * Dp[j];
+                        if (STATS && K >= 4) bytes3 += per_arc + 4ull * Dp[j];
                         if (K == 3) tri += 1;
                     }
                 }
@@ -1440,21 +1473,231 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
         }
         wave_lds_sync();
     }
-    // merge-model bytes: level 2 of the rows built here, level 1 once per root
-    for (int i = i0 + tid; i < i_end; i += 256) bytes += 8ull + 4ull * ((uint64_t)d + Dp[i]);
-    if (i0 == 0 && tid == 0) bytes += 4ull + 4ull * (uint64_t)d;
-    bytes = wave_sum_u64(bytes);
-    bytes3 = wave_sum_u64(bytes3);
-    tri = wave_sum_u64(tri);
+    if (STATS) {  // merge-model bytes: level 2 of the rows built here, level 1 once per root
+        for (int i = i0 + tid; i < i_end; i += 256) bytes += 8ull + 4ull * ((uint64_t)d + Dp[i]);
+        if (i0 == 0 && tid == 0) bytes += 4ull + 4ull * (uint64_t)d;
+        bytes = wave_sum_u64(bytes);
+        bytes3 = wave_sum_u64(bytes3);
+    }
+    if (K == 3) tri = wave_sum_u64(tri);
     if (lane == 0) {
-        if (bytes) atomicAdd(alg_bytes + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)bytes);
-        if (bytes3) atomicAdd(alg_bytes3 + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)bytes3);
+        if (STATS && bytes) atomicAdd(alg_bytes + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)bytes);
+        if (STATS && bytes3) atomicAdd(alg_bytes3 + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)bytes3);
         if (K == 3 && tri) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)tri);
     }
 }
 
+// The same rows built from the adjacency lists instead of the hub matrix:
+// row i = N+(U[i]) ^ U by streaming the list N+(U[i]) with coalesced reads and
+// testing every entry against a bitmap of U held in LDS (one LDS read and a
+// shift per entry).  The position in U of an entry that passes is its rank
+// among the set bits: a prefix count per bitmap word plus a popcount, so a hit
+// costs one more LDS read, no search.  A gathered bit costs a 128-byte line of
+// the hub matrix unless neighbouring lanes share it, which for universes of a
+// few hundred vertices they rarely do; a list entry costs 4 bytes.
+//
+// The bitmap covers the ids [base_id, base_id + 32 * bm_words): the host passes
+// the lowest root of the chunk as base_id (universes only hold vertices above
+// their root) and sizes the LDS for it.
+//
+// grid = nroots * RB workgroups of 256 threads; workgroup (ri, rb) builds the
+// rows i = rb (mod RB) of root ri, its four waves taking them in turn.  The
+// list ranges of 64 rows are fetched at once (one row per lane); a row's first
+// 512 entries are in flight while the row before it is tested.
+// LDS (words): bitmap[bm_words] | prefix[bm_words / 2] (16-bit) | U[dcap] | stage[4][128].
+#define CLQ_BM_MAX_WORDS 16384  // ids a bitmap can cover: 2^19
+#define CLQ_LIST_LOADS 8        // list reads in flight per lane and row
+
+template <int K>
+__global__ __launch_bounds__(256) void k_clq_build_lists(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
+                                                         int RB, int32_t base_id, int bm_words, uint32_t *rows_buf,
+                                                         int64_t stride_words, unsigned long long *n_matches) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ uint32_t s_wave_sum[4];
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
+    const int64_t ri = blockIdx.x / RB;
+    const int rb = (int)(blockIdx.x % RB);
+    if (ri >= nroots) return;
+    const int64_t *off = g.off[0], *mid = g.mid[0];
+    const int32_t *adj = g.adj[0];
+    const int32_t u = roots[ri];
+    const int64_t ub = mid[u];
+    const int d = (int)(off[u + 1] - ub);
+    if (rb >= d) return;
+    uint32_t *bm = smem;                                                  // bm_words is a multiple of 1024
+    uint16_t *prefix = reinterpret_cast<uint16_t *>(smem + bm_words);     // set bits before each bitmap word
+    int32_t *U = (int32_t *)(smem + bm_words + bm_words / 2);
+    uint32_t *stage = smem + bm_words + bm_words / 2 + dcap + wave * 128;
+    for (int k = tid; k < bm_words / 4; k += 256) reinterpret_cast<uint4 *>(bm)[k] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    for (int i = tid; i < d; i += 256) {
+        const int32_t v = adj[ub + i];
+        U[i] = v;
+        const uint32_t c = (uint32_t)(v - base_id);
+        atomicOr(bm + (c >> 5), 1u << (c & 31));
+    }
+    __syncthreads();
+    {  // prefix counts: every thread sums its run of words, the runs are scanned, the words filled in
+        const int wpt = bm_words / 256;
+        uint32_t mine = 0;
+        for (int k = 0; k < wpt; ++k) mine += __popc(bm[tid * wpt + k]);
+        uint32_t incl = mine;
+        for (int o = 1; o < GPM_WAVE; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, GPM_WAVE);
+            if (lane >= o) incl += up;
+        }
+        if (lane == GPM_WAVE - 1) s_wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (int w = 0; w < wave; ++w) before += s_wave_sum[w];
+        for (int k = 0; k < wpt; ++k) {
+            prefix[tid * wpt + k] = (uint16_t)before;
+            before += __popc(bm[tid * wpt + k]);
+        }
+    }
+    __syncthreads();
+
+    const int T = big_tiles(d);
+    uint32_t *region = rows_buf + ri * stride_words;
+    uint64_t tri = 0;
+    const int step = 4 * RB;               // distance between two rows of one wave
+    const int first = rb + RB * wave;      // this wave's first row
+    for (int i_batch = first; i_batch < d; i_batch += 64 * step) {
+        // list ranges of the next 64 rows of this wave, one row per lane
+        int64_t my_b = 0;
+        int my_n = 0;
+        {
+            const int i_l = i_batch + lane * step;
+            if (i_l < d) {
+                const int32_t v = U[i_l];
+                my_b = mid[v];
+                my_n = (int)(off[v + 1] - my_b);
+            }
+        }
+        const uint32_t my_b_lo = (uint32_t)my_b, my_b_hi = (uint32_t)((uint64_t)my_b >> 32);
+        auto range_of = [&](int r, int64_t &b, int &n) {
+            b = (int64_t)(((uint64_t)__builtin_amdgcn_readlane(my_b_hi, r) << 32) | __builtin_amdgcn_readlane(my_b_lo, r));
+            n = __builtin_amdgcn_readlane(my_n, r);
+        };
+        int32_t cur[CLQ_LIST_LOADS], nxt[CLQ_LIST_LOADS];
+        int64_t b;
+        int n;
+        range_of(0, b, n);
+#pragma unroll
+        for (int k = 0; k < CLQ_LIST_LOADS; ++k) {
+            const int p = k * GPM_WAVE + lane;
+            cur[k] = p < n ? adj[b + p] : -1;
+        }
+        for (int r = 0; r < 64; ++r) {
+            const int i = i_batch + r * step;
+            if (i >= d) break;
+            int64_t nb = 0;
+            int nn = 0;
+            if (r + 1 < 64 && i + step < d) range_of(r + 1, nb, nn);
+#pragma unroll
+            for (int k = 0; k < CLQ_LIST_LOADS; ++k) {  // the next row's entries are in flight while this row is tested
+                const int p = k * GPM_WAVE + lane;
+                nxt[k] = p < nn ? adj[nb + p] : -1;
+            }
+            if (K != 3) {
+                stage[lane] = 0;
+                stage[GPM_WAVE + lane] = 0;
+                wave_lds_sync();
+            }
+            auto test = [&](int32_t w) {
+                if (w < 0) return;
+                const uint32_t c = (uint32_t)(w - base_id);
+                const uint32_t word = bm[c >> 5], bit = 1u << (c & 31);
+                if (!(word & bit)) return;
+                if (K == 3) {
+                    tri += 1;
+                } else {
+                    const int j = (int)prefix[c >> 5] + __popc(word & (bit - 1));  // rank among the set bits = position in U
+                    atomicOr(stage + (j >> 5), 1u << (j & 31));
+                }
+            };
+#pragma unroll
+            for (int k = 0; k < CLQ_LIST_LOADS; ++k) test(cur[k]);
+            for (int p0 = CLQ_LIST_LOADS * GPM_WAVE; p0 < n; p0 += 4 * GPM_WAVE) {  // the rest of a long list
+                int32_t w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int p = p0 + k * GPM_WAVE + lane;
+                    w[k] = p < n ? adj[b + p] : -1;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) test(w[k]);
+            }
+            if (K != 3) {
+                wave_lds_sync();
+                for (int t = 0; t < T; ++t) {
+                    const int Wt = big_words(d, t);
+                    if (i < big_rows(d, t) && lane < Wt) region[big_off(t) + (int64_t)i * Wt + lane] = stage[32 * t + lane];
+                }
+                wave_lds_sync();
+            }
+#pragma unroll
+            for (int k = 0; k < CLQ_LIST_LOADS; ++k) cur[k] = nxt[k];
+            b = nb;
+            n = nn;
+        }
+    }
+    if (K == 3) {
+        tri = wave_sum_u64(tri);
+        if (lane == 0 && tri) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)tri);
+    }
+}
+
+// popc(x) + acc in one instruction (the compiler otherwise counts into a fresh register and adds).
+__device__ __forceinline__ uint32_t popc_add(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t and_popc_add4(u32x4 c, u32x4 r, uint32_t acc) {
+    acc = popc_add(c.x & r.x, acc);
+    acc = popc_add(c.y & r.y, acc);
+    acc = popc_add(c.z & r.z, acc);
+    return popc_add(c.w & r.w, acc);
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave with data-parallel-primitive adds: four shifts inside
+// the rows of 16 lanes, then the row totals carried into the rows above.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 // grid = nroots * phases * SEG workgroups of NW waves (phases = 1 for
-// dcap <= 1024, else 3).  LDS (words): J[NW][512] (16-bit entries) | tile rows.
+// dcap <= 1024, else the tile pairs).  LDS (words): J[NW][512] (16-bit entries)
+// | tile rows.
+//
+// For every row i the wave first lists the set bits j of row i over the row
+// tile (the rows j to AND with), then lane blocks of L lanes each take entries
+// of the list, read row j's words over the column tile from LDS, 16 bytes per
+// lane, and add |row_i ^ row_j|.
+//
+// Listing.  Lane l holds 16 of the row's 1024 positions; an inclusive scan of
+// the per-lane bit counts over the wave gives every lane the place of its first
+// entry, and each lane then writes its own entries (the order inside a list
+// does not matter).  List entries are row offsets in 16-byte slots (j * L), so
+// a row's address is one shift-add.
+//
+// LDS layout and lane mapping.  A tile row is held at a stride of L slots,
+// L = lanes per row = its words / 4 rounded up to a power of two.  The LDS
+// serves a 16-byte-per-lane read in four groups of 16 lanes, each group one
+// cycle when its lanes touch 16 different slots (slot = 16-byte address mod
+// 16).  With L = 8 (the 1024-column tiles) a group holds half rows of four lane
+// blocks, two lower and two upper halves, and two rows clash exactly when they
+// have the same parity: the set bits are therefore listed by parity, and of the
+// four blocks of a group two always read even rows and two odd rows.  Each
+// parity list is read by four blocks per instruction.  Narrower tiles (L < 8)
+// use one list.
 template <int SEG, int NW>
 __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
                                                     const uint32_t *rows_buf, int64_t stride_words,
@@ -1487,49 +1730,92 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
     const uint32_t *tile_rows = xsrc + (size_t)j_lo * Wt;        // rows j_lo.. of the column tile
     uint16_t *J = (uint16_t *)smem + wave * 1024;
     uint32_t *tile = smem + NW * 512;
+    const int lg = Wt <= 4 ? 0 : Wt <= 8 ? 1 : Wt <= 16 ? 2 : 3;  // Wt <= 32
+    const int L = 1 << lg, sub = lane & (L - 1), blk = lane >> lg;
+    const bool lane_ok = 4 * sub < Wt;
     {
-        const int nvec = (j_hi - j_lo) * Wt / 4;
+        // rows copied in at a stride of L slots; the slots past a row's Wt / 4 are never read
+        const int nslots = (j_hi - j_lo) << lg, Wq = Wt >> 2;
         const uint4 *src = reinterpret_cast<const uint4 *>(tile_rows);
         uint4 *dst = reinterpret_cast<uint4 *>(tile);
-        for (int k = tid; k < nvec; k += NW * GPM_WAVE) dst[k] = src[k];
+        constexpr int NT = NW * GPM_WAVE, FILL = 8;  // eight 16-byte reads in flight per thread
+        for (int k0 = tid; k0 < nslots; k0 += FILL * NT) {
+            uint4 v[FILL];
+#pragma unroll
+            for (int f = 0; f < FILL; ++f) {
+                const int k = k0 + f * NT, row = k >> lg, s4 = k & (L - 1);
+                if (k < nslots && s4 < Wq) v[f] = src[row * Wq + s4];
+            }
+#pragma unroll
+            for (int f = 0; f < FILL; ++f) {
+                const int k = k0 + f * NT, s4 = k & (L - 1);
+                if (k < nslots && s4 < Wq) dst[k] = v[f];
+            }
+        }
     }
     __syncthreads();
 
-    const int lg = Wt <= 4 ? 0 : Wt <= 8 ? 1 : Wt <= 16 ? 2 : Wt <= 32 ? 3 : 4;
-    const int L = 1 << lg, G = GPM_WAVE >> lg, sub = lane & (L - 1);
-    const bool lane_ok = 4 * sub < Wt;
+    const bool two = lg == 3;  // two lists, by parity of j
+    // reading: list and first entry of this lane block, entries per step
+    const int my_res = two ? (blk >> 1) & 1 : 0;
+    const int my_first = two ? (blk & 1) + 2 * (blk >> 2) : blk;
+    const int my_step = two ? 4 : GPM_WAVE >> lg;
+    const uint16_t *Jmine = J + 512 * my_res;
+    // listing: this lane's 16 positions
+    const int word_of_lane = lane & 31, half_of_lane = lane >> 5;
+    const uint32_t pos0 = (uint32_t)(32 * word_of_lane + 16 * half_of_lane);
+    const uint32_t *lane_base = tile + 4 * sub;
+
     uint64_t total = 0;
     const int step = SEG * NW;
     int i = seg * NW + wave;
-    // row i's list words (lane l holds word l) and its column-tile words, fetched one row ahead
+    // row i's list words (lanes l and l + 32 hold word l) and its column-tile words, fetched one row ahead
     uint32_t mine = 0;
     u32x4 C = {0u, 0u, 0u, 0u};
     if (i < i_hi) {
-        if (lane < Wj) mine = jsrc[(size_t)i * Wj + lane];
+        if (word_of_lane < Wj) mine = jsrc[(size_t)i * Wj + word_of_lane];
         if (lane_ok) C = load4(xsrc + (size_t)i * Wt + 4 * sub);
     }
     while (i < i_hi) {
+        // list the set bits of row i over tile a
+        uint32_t bits = (mine >> (16 * half_of_lane)) & 0xffffu;
+        const uint32_t c = two ? (uint32_t)__popc(bits & 0x5555u) | ((uint32_t)__popc(bits & 0xaaaau) << 16)
+                               : (uint32_t)__popc(bits);
+        const uint32_t incl = wave_incl_scan_u32(c);
+        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, GPM_WAVE - 1);
+        uint32_t at0 = (incl - c) & 0xffffu, at1 = 512u + ((incl - c) >> 16);  // next free entry, even / odd list
+        while (bits) {
+            const uint32_t b = (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1;
+            const bool odd = two && (b & 1u);
+            J[odd ? at1 : at0] = (uint16_t)((pos0 + b) << lg);
+            at1 += odd;
+            at0 += !odd;
+        }
+        // the next row's words are requested once this row's have been used
         const int inext = i + step;
         uint32_t mine_n = 0;
         u32x4 C_n = {0u, 0u, 0u, 0u};
         if (inext < i_hi) {
-            if (lane < Wj) mine_n = jsrc[(size_t)inext * Wj + lane];
+            if (word_of_lane < Wj) mine_n = jsrc[(size_t)inext * Wj + word_of_lane];
             if (lane_ok) C_n = load4(xsrc + (size_t)inext * Wt + 4 * sub);
         }
-        const int cnt = clq_expand_reg(mine, Wj, J, lane);
+        const int my_len = (int)(my_res ? all >> 16 : all & 0xffffu);
         wave_lds_sync();
-        if (cnt && lane_ok) {
-            const uint32_t *base = tile + 4 * sub;
+        if (all && lane_ok) {
             uint32_t acc = 0;
-            int t = lane >> lg;
-            for (; t + 3 * G < cnt; t += 4 * G) {
-                u32x4 r0 = load4(base + (size_t)J[t] * Wt);
-                u32x4 r1 = load4(base + (size_t)J[t + G] * Wt);
-                u32x4 r2 = load4(base + (size_t)J[t + 2 * G] * Wt);
-                u32x4 r3 = load4(base + (size_t)J[t + 3 * G] * Wt);
-                acc += popc4(and4(C, r0)) + popc4(and4(C, r1)) + popc4(and4(C, r2)) + popc4(and4(C, r3));
+            int t = my_first;
+            for (; t + 3 * my_step < my_len; t += 4 * my_step) {  // four independent row reads in flight
+                const u32x4 r0 = load4(lane_base + ((uint32_t)Jmine[t] << 2));
+                const u32x4 r1 = load4(lane_base + ((uint32_t)Jmine[t + my_step] << 2));
+                const u32x4 r2 = load4(lane_base + ((uint32_t)Jmine[t + 2 * my_step] << 2));
+                const u32x4 r3 = load4(lane_base + ((uint32_t)Jmine[t + 3 * my_step] << 2));
+                acc = and_popc_add4(C, r0, acc);
+                acc = and_popc_add4(C, r1, acc);
+                acc = and_popc_add4(C, r2, acc);
+                acc = and_popc_add4(C, r3, acc);
             }
-            for (; t < cnt; t += G) acc += popc4(and4(C, load4(base + (size_t)J[t] * Wt)));
+            for (; t < my_len; t += my_step) acc = and_popc_add4(C, load4(lane_base + ((uint32_t)Jmine[t] << 2)), acc);
             total += acc;
         }
         wave_lds_sync();

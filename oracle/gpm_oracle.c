@@ -204,6 +204,7 @@ int oracle_parse_file(const char *path, OGraph **data, OGraph **pattern,
 typedef struct {
     const OGraph *g, *p;
     int fast;
+    int prune;         /* fast == 2: test a vertex's label when it is bound instead of on complete matches */
     int **sout, **sin; /* sorted copies for fast membership */
     int symmetric;     /* data graph: in-list == out-list as sets for all v */
     const int *dl, *pl;
@@ -319,6 +320,10 @@ static void explore(Search *s, int depth, int *m) {
     s->st.alg_bytes += level_bytes(s, depth + 1, pv, parent, signed_next < 0, m);
     for (int i = 0; i < ncand; ++i) {
         int c = cand[i];
+        /* The label filter keeps a complete match iff every vertex carries its pattern vertex's label, so
+         * a candidate with the wrong label can be dropped here: the surviving matches and their order
+         * are those of the post-filter (the per-level statistics then count the pruned search). */
+        if (s->prune && s->dl[c] != s->pl[pv]) continue;
         if (candidate_ok(s, c, pv, m)) {
             int m2[ORACLE_MAX_PATTERN + 1]; /* addNode, src/gpm-par.c:169-177 */
             memcpy(m2, m, sizeof m2);
@@ -368,6 +373,7 @@ long long oracle_search(const OGraph *data, const OGraph *pattern, int fast,
     s.g = data;
     s.p = pattern;
     s.fast = fast;
+    s.prune = fast == 2 && data_labels && pattern_labels;
     s.dl = data_labels;
     s.pl = pattern_labels;
     s.rows = rows;
@@ -387,6 +393,7 @@ long long oracle_search(const OGraph *data, const OGraph *pattern, int fast,
     /* reference: findMatches, src/gpm-par.c:245-252 -- every vertex is a
      * root for pattern vertex 1, ascending id. */
     for (int v = root_lo; v <= root_hi; ++v) {
+        if (s.prune && data_labels[v] != pattern_labels[1]) continue;
         int m[ORACLE_MAX_PATTERN + 1];
         for (int i = 0; i <= ORACLE_MAX_PATTERN; ++i) m[i] = -1;
         m[1] = v;

@@ -72,7 +72,11 @@ int oracle_parse_file(const char *path, OGraph **data, OGraph **pattern,
  *   out      : optional FILE* receiving one line per match.
  *   fast     : 0 = linear membership scans like the reference
  *              (utils.c:46-53); 1 = binary search on sorted copies (same
- *              results and order, used for larger test inputs).
+ *              results and order, used for larger test inputs); 2 = as 1,
+ *              and with labels a vertex's label is tested when the vertex is
+ *              bound, which drops whole subtrees the post-filter would have
+ *              enumerated and thrown away (same matches, same order; the
+ *              statistics then describe the pruned search).
  *   data_labels/pattern_labels: NULL, or label filter (a match is kept iff
  *              label_G(m(i)) == label_P(i) for every i); applied as a
  *              post-filter on complete matches.

@@ -116,6 +116,64 @@ def test_golden_counts_and_multisets(spec):
     m.close()
 
 
+LARGE = util.golden_large_specs()
+KIND_CLQ_BUILD, KIND_CLQ_COUNT, KIND_CYCLE4 = 3, 4, 5  # GPM_KIND_* of include/gpm_hip.h
+# device paths a large vector is run through: (environment, accounting on, kernel families that must have run)
+LARGE_PATHS = {
+    "clique4": [({}, True, ()), ({}, False, ()),
+                # universes above 24 vertices through the build / count pair: rows gathered from the hub matrix ...
+                ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_MAX_CLASS": "1"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
+                ({"GPM_CLIQUE_SMALL_MAX": "24"}, True, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
+                # ... and built from the adjacency lists
+                ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_MAX_CLASS": "5"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
+                ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_COUNT4_WAVES": "8"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT))],
+    "triangle": [({}, True, ()), ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_MAX_CLASS": "1"}, False, (KIND_CLQ_BUILD,)),
+                 ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_MAX_CLASS": "5"}, False, (KIND_CLQ_BUILD,))],
+    "cycle4": [({}, True, (KIND_CYCLE4,)), ({"GPM_CYCLE4_HEAVY": "4096"}, True, (KIND_CYCLE4,))],
+}
+
+
+@pytest.mark.parametrize("spec", LARGE, ids=[g["name"] for g in LARGE])
+def test_large_goldens(spec, monkeypatch):
+    """Counts (and, up to a few million matches, the multiset of rows by checksum) of vectors captured
+    from the compiled reference through a pipe -- or, where marked so, from the pinned oracle -- with
+    10^6 .. 10^9 matches, through the kernels the headline benchmarks use: the asserted kernel
+    families must have launched."""
+    n, s, d = util.build_graph(spec)
+    dl, pl = util.build_labels(spec, n)
+    for env, accounting, kinds in LARGE_PATHS.get(spec["pattern"], [({}, True, ())]):
+        for k in ("GPM_CLIQUE_SMALL_MAX", "GPM_CLQ_LISTS_MAX_CLASS", "GPM_COUNT4_WAVES", "GPM_CYCLE4_HEAVY"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = binding.Matcher(1)
+        m.set_accounting(accounting)
+        upload(m, n, s, d, labels=dl)
+        m.set_pattern(gen.PATTERNS[spec["pattern"]], labels=pl)
+        assert m.findMatches(count_only=True) == spec["count"], (spec["name"], env)
+        st = m.stats()
+        for kind in kinds:
+            assert st.kernel_launches[kind] > 0, (spec["name"], env, kind)
+        if spec["count"] <= 5_000_000 and not env:
+            rows = m.findMatches(count_only=False)
+            assert len(rows) == spec["count"]
+            assert util.rows_multiset_hash(rows) == spec["rows_hash"]
+        m.close()
+
+
+def test_labelled_tree_on_the_16_label_twin_through_the_program(tmp_path):
+    """Config 4's twin (n = 2^14 power-law graph, 16 labels) through gpm-par.exe: the labels trailer,
+    label segments on and off, closed-form leaves on and off."""
+    spec = next(g for g in LARGE if g["name"] == "plaw14_tree5_labelled16")
+    text, _, _ = util.build_input(spec)
+    for env in ({}, {"GPM_NO_LABEL_SEGMENTS": "1"}, {"GPM_NO_LEAF_SUFFIX": "1"}):
+        _, got = run_cli(text, tmp_path, env=env)
+        assert got.count(b"\n") == spec["count"], env
+        import io
+        count, h = util.text_multiset_hash(io.BytesIO(got), 5)
+        assert (count, h) == (spec["count"], spec["rows_hash"]), env
+
+
 CLI_GOLDEN = [g for g in GOLDEN if g["name"] in ("er10k_triangle", "rmat10_clique4", "rmat8_house",
                                                  "plaw9_tree5_labelled4", "rand40_dir_tree5_dir")]
 

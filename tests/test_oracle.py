@@ -75,3 +75,35 @@ def test_label_filter_is_a_post_filter():
     keep = np.all(dl[rows - 1] == np.array(pl)[None, :], axis=1)
     _, lrows, _ = util.oracle_matches(n, s, d, pat, data_labels=dl, pattern_labels=pl)
     assert np.array_equal(rows[keep], lrows)
+
+
+@pytest.mark.parametrize("pname,plabels", [("path3", [0, 1, 2]), ("tree5", [0, 1, 2, 3, 1]), ("triangle", [1, 1, 0]),
+                                           ("tree5_dir", [0, 0, 1, 2, 1]), ("cycle4", [0, 1, 0, 1])])
+def test_label_pruning_gives_the_post_filtered_rows_in_the_same_order(pname, plabels):
+    """fast = 2 tests labels while vertices are bound; the rows and their order are those of the
+    post-filter (fast = 1), which in turn is pinned to the reference's filtered output."""
+    n, s, d = util.build_graph({"graph": "plaw", "n": 256, "avg_deg": 6, "seed": 2})
+    if pname == "tree5_dir":
+        s, d = util.rand_digraph(60, 1, 5, 4, False)
+        n = 60
+    dl = gen.vertex_labels(n, 4, seed=2).numpy().astype(np.int32)
+    pat = gen.PATTERNS[pname]
+    c1, r1, _ = util.oracle_matches(n, s, d, pat, fast=1, data_labels=dl, pattern_labels=plabels)
+    c2, r2, _ = util.oracle_matches(n, s, d, pat, fast=2, data_labels=dl, pattern_labels=plabels)
+    assert c1 == c2 and np.array_equal(r1, r2)
+
+
+LARGE_SMALL_ENOUGH = [g for g in util.golden_large_specs() if g["count"] <= 5_000_000]
+
+
+@pytest.mark.parametrize("spec", LARGE_SMALL_ENOUGH, ids=[g["name"] for g in LARGE_SMALL_ENOUGH])
+def test_oracle_equals_the_large_vectors_it_can_afford(spec):
+    """Count and row checksum of the captured vectors with up to a few million matches (the labelled
+    ones with the label test applied while binding; the 16-label vector on the small graph was
+    captured from the reference's unlabelled output, filtered)."""
+    n, s, d = util.build_graph(spec)
+    dl, pl = util.build_labels(spec, n)
+    cnt, rows, _ = util.oracle_matches(n, s, d, gen.PATTERNS[spec["pattern"]], fast=2 if dl is not None else 1,
+                                       data_labels=dl, pattern_labels=pl, cap=spec["count"] + 1)
+    assert cnt == spec["count"]
+    assert util.rows_multiset_hash(rows) == spec["rows_hash"]

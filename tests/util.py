@@ -27,6 +27,13 @@ def golden_specs():
         return json.load(f)
 
 
+def golden_large_specs():
+    """Vectors whose outputs are too large to keep: count and order-independent row checksum
+    (tests/golden/make_golden_large.py)."""
+    with open(os.path.join(GOLDEN_DIR, "golden_large.json")) as f:
+        return json.load(f)
+
+
 def small_cases():
     d = os.path.join(GOLDEN_DIR, "small")
     return sorted(f[:-3] for f in os.listdir(d) if f.endswith(".in"))
@@ -186,6 +193,48 @@ def rows_to_text(rows: np.ndarray) -> bytes:
 
 def sorted_lines_md5(b: bytes) -> str:
     return md5(b"".join(sorted(b.splitlines(keepends=True))))
+
+
+_SM_GOLD, _SM_M1, _SM_M2 = np.uint64(0x9E3779B97F4A7C15), np.uint64(0xBF58476D1CE4E5B9), np.uint64(0x94D049BB133111EB)
+
+
+def _mix64(z):
+    z = z + _SM_GOLD
+    z = (z ^ (z >> np.uint64(30))) * _SM_M1
+    z = (z ^ (z >> np.uint64(27))) * _SM_M2
+    return z ^ (z >> np.uint64(31))
+
+
+def rows_multiset_hash(rows: np.ndarray) -> int:
+    """Order-independent checksum of match rows: every row is hashed (a chain of 64-bit mixes over
+    its columns), the row hashes are added modulo 2^64.  Equal multisets of rows give equal sums
+    whatever the order the rows arrive in, so it can be accumulated block by block."""
+    with np.errstate(over="ignore"):
+        r = np.ascontiguousarray(rows).astype(np.uint64)
+        h = np.zeros(len(r), dtype=np.uint64)
+        for c in range(r.shape[1]):
+            h = _mix64(h ^ r[:, c])
+        return int(h.sum(dtype=np.uint64))
+
+
+def text_multiset_hash(stream, ncols: int, block: int = 1 << 26):
+    """(line count, rows_multiset_hash) of output lines read from a binary stream, block by block."""
+    count, total, carry = 0, 0, b""
+    while True:
+        buf = stream.read(block)
+        if not buf:
+            break
+        buf = carry + buf
+        cut = buf.rfind(b"\n") + 1
+        carry, buf = buf[cut:], buf[:cut]
+        if not buf:
+            continue
+        vals = np.fromstring(buf.decode(), dtype=np.int64, sep=" ")
+        rows = vals.reshape(-1, ncols)
+        count += len(rows)
+        total = (total + rows_multiset_hash(rows)) & ((1 << 64) - 1)
+    assert not carry.strip(), "output does not end with a newline"
+    return count, total
 
 
 def brute_force(n, src0, dst0, pattern):
