@@ -2,32 +2,31 @@
 """Headline benchmark: embeddings of the 4-clique found per second on an R-MAT
 scale-24 graph (edge factor 16), count-only, on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
-One process per GPU.  Every rank builds the same synthetic graph on its own
+One process per GPU.  Started from a plain shell with N > 1, the script
+launches its N ranks itself (`python -m torch.distributed.run`, rendezvous on
+127.0.0.1) before anything touches a GPU; started by torch.distributed.run it
+is one of the ranks.  Every rank builds the same synthetic graph on its own
 GPU (deterministic generator), uploads it through the C ABI, and all ranks
 take root chunks from one shared cursor; the only exchange is an all-reduce
 of the counts (RCCL when N > 1).  A step is one complete search of the graph;
 the graph is resident in HBM before the timed region.  Rank 0 prints one JSON
-line.
+line and exits non-zero when the count is not the expected one.
 """
 import argparse
+import hashlib
 import json
 import os
 import shutil
+import socket
 import subprocess
 import sys
 import tempfile
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from mpi_amd import binding, dist as gdist, gen  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
@@ -39,7 +38,7 @@ def log(*a):
 # The five benchmark configurations: data graph, pattern, and the scaled-down twin the CPU baseline runs on.
 CONFIGS = {
     1: {"graph": {"graph": "er", "n": 10000, "m": 50000, "seed": 1}, "pattern": "triangle",
-        "twin": {"graph": "er", "n": 10000, "m": 50000, "seed": 1}},
+        "twin": {"graph": "er", "n": 10000, "m": 50000, "seed": 1}, "baseline_ranks": 4},
     2: {"graph": {"graph": "rmat", "scale": 20, "ef": 16, "seed": 1}, "pattern": "cycle4",
         "twin": {"graph": "rmat", "scale": 9, "ef": 16, "seed": 1}},
     3: {"graph": {"graph": "rmat", "scale": 24, "ef": 16, "seed": 1}, "pattern": "clique4",
@@ -50,6 +49,36 @@ CONFIGS = {
         "pattern": "k6_minus_pm",
         "twin": {"graph": "rmat", "scale": 9, "ef": 8, "abcd": (0.7, 0.1, 0.1, 0.1), "seed": 1}},
 }
+
+# Embeddings of every configuration at full size.  No CPU program can enumerate them; they are what the
+# independent device paths agree on (bitmap / two-path / closed-form kernels against the level-by-level
+# kernels), and the same kernels reproduce the captured vectors of tests/golden at the sizes a CPU can reach.
+EXPECTED_FULL = {1: 924, 2: 3614591580112, 3: 21123390052368, 4: 20278778911046, 5: 235455970772256}
+
+
+def spec_key(graph, pattern, labels=None, pattern_labels=None):
+    g = {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in graph.items()}
+    return json.dumps({"graph": g, "pattern": pattern, "labels": labels,
+                       "pattern_labels": list(pattern_labels) if pattern_labels else None}, sort_keys=True)
+
+
+def expected_count(config, cfg, overridden, labelled):
+    """(count, where it comes from) for the workload about to run, or (None, None)."""
+    if not overridden:
+        return EXPECTED_FULL[config], "count the device paths agree on at full size (bench.py EXPECTED_FULL)"
+    want = spec_key(cfg["graph"], cfg["pattern"], cfg.get("labels") if labelled else None,
+                    cfg.get("pattern_labels") if labelled else None)
+    for name in ("golden.json", "golden_large.json"):
+        path = os.path.join(ROOT, "tests", "golden", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            for g in json.load(f):
+                graph = {k: g[k] for k in ("graph", "n", "m", "scale", "ef", "abcd", "avg_deg", "seed", "p", "symmetric")
+                         if k in g}
+                if spec_key(graph, g["pattern"], g.get("labels"), g.get("pattern_labels")) == want:
+                    return g["count"], f"tests/golden/{name}: {g['name']} ({g.get('source', 'reference')})"
+    return None, None
 
 
 def describe(spec):
@@ -64,6 +93,7 @@ def describe(spec):
 
 def generate(spec, device):
     """CSR (offsets, adjacency) of a benchmark graph, built on `device`."""
+    from mpi_amd import gen
     if spec["graph"] == "er":
         return spec["n"], *gen.erdos_renyi(spec["n"], spec["m"], seed=spec["seed"], device=device)
     if spec["graph"] == "rmat":
@@ -72,44 +102,50 @@ def generate(spec, device):
     return spec["n"], *gen.power_law(spec["n"], avg_deg=spec["avg_deg"], seed=spec["seed"], device=device)
 
 
-def cpu_baseline_many_ranks(cfg, ranks, budget_s=150):
-    """The reference under `mpirun -np <ranks>` on the same twin (its vertex partitioning and remote
-    adjacency fetches at work).  Uses the build that keeps the payload of its fire-and-forget sends
-    alive (oracle/ref_isend_fix.c); the untouched reference crashes with three or more ranks."""
-    from tests import util  # noqa: F401  (keeps the import pattern of cpu_baseline)
-    n, off, adj = generate(cfg["twin"], "cpu")
-    s, d = gen.edges_from_csr(*gen.csr_to_numpy(off, adj))
-    ref = os.path.join(ROOT, "oracle", "_ref", "gpm-par-ref-k")
+# ---- CPU baseline -----------------------------------------------------------
+
+def host_cores():
+    """(cores the machine reports, cores this job may use).  On a shared box the second is the smaller:
+    thread-count variables set by the operator bound it."""
+    total = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else total
+    for var in ("OMP_NUM_THREADS", "MAX_JOBS"):
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) > 0:
+            usable = min(usable, int(v))
+    return total, usable
+
+
+def count_lines(path):
+    with open(path, "rb") as f:
+        return sum(chunk.count(b"\n") for chunk in iter(lambda: f.read(1 << 24), b""))
+
+
+def run_reference(binary, ranks, inp, out, budget_s):
+    """Wall seconds of `mpirun -np <ranks> <binary> inp out`, None when it ran out of budget."""
     mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
-    if "labels" in cfg or not (os.path.exists(ref) and os.path.exists(mpirun)):
+    t0 = time.time()
+    try:
+        subprocess.run([mpirun, "-np", str(ranks), binary, inp, out], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=budget_s)
+    except subprocess.TimeoutExpired:
         return None
-    with tempfile.TemporaryDirectory() as tmp:
-        inp, out = os.path.join(tmp, "in.txt"), os.path.join(tmp, "out.txt")
-        gen.write_input(inp, n, s, d, gen.PATTERNS[cfg["pattern"]])
-        t0 = time.time()
-        try:
-            subprocess.run([mpirun, "-np", str(ranks), ref, inp, out], check=True, stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, timeout=budget_s)
-        except subprocess.TimeoutExpired:
-            return {"value": None, "unit": "matches/s", "cores": ranks, "kind": "reference",
-                    "sample": f"{describe(cfg['twin'])}, {cfg['pattern']}: did not finish in {budget_s} s"}
-        except Exception as e:  # noqa: BLE001
-            log(f"reference at {ranks} ranks failed: {e!r}")
-            return None
-        dt = time.time() - t0
-        with open(out, "rb") as f:
-            count = sum(chunk.count(b"\n") for chunk in iter(lambda: f.read(1 << 24), b""))
-        return {"value": count / dt, "unit": "matches/s", "cores": ranks, "kind": "reference",
-                "sample": f"{describe(cfg['twin'])} twin of the workload, {cfg['pattern']}, full output to a file, "
-                          f"mpirun -np {ranks}", "matches": count, "seconds": round(dt, 3)}
+    return time.time() - t0
 
 
-def cpu_baseline(cfg, budget_s=120):
-    """The reference (built from its own sources into oracle/_ref) timed under
-    `mpirun -np 2` -- one worker, its fastest configuration -- on a scaled-down
-    twin of the workload; falls back to the oracle (a port) when the reference
-    binary or mpirun is not available, and for labelled patterns, which the
-    reference cannot read."""
+def cpu_baseline(cfg, budget_s=120, many_budget_s=60, forced_many=0):
+    """The reference (built from its own sources into oracle/_ref) timed beside the GPU run on a scaled-down
+    twin of the workload, full output to a file:
+      * `mpirun -np 2` -- one worker, its fastest setting (it scales negatively: every candidate a worker does
+        not own costs an MPI round trip, reference: src/gpm-par.c:223-229); configuration 1 uses `-np 4`, the
+        setting its definition names;
+      * `mpirun -np K`, K = min(cores this job may use, 64), with the build that keeps the payload of its
+        fire-and-forget sends alive (oracle/ref_isend_fix.c; the untouched reference crashes at K >= 3),
+        under a budget: "DNF" when it does not finish.
+    Falls back to the oracle (a port) when the reference binary or mpirun is missing, and for labelled
+    patterns, which the reference cannot read."""
+    import numpy as np
+    from mpi_amd import gen
     from tests import util
     pattern_name = cfg["pattern"]
     n, off, adj = generate(cfg["twin"], "cpu")
@@ -119,25 +155,39 @@ def cpu_baseline(cfg, budget_s=120):
     if "labels" in cfg:
         dl = gen.vertex_labels(n, cfg["labels"], seed=cfg["twin"]["seed"]).numpy().astype(np.int32)
         pl = cfg["pattern_labels"]
+    total_cores, usable = host_cores()
     sample = f"{describe(cfg['twin'])} twin of the workload, {pattern_name}, full output to a file"
+    ref = os.path.join(ROOT, "oracle", "_ref", "gpm-par-ref")
+    ref_k = os.path.join(ROOT, "oracle", "_ref", "gpm-par-ref-k")
+    mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
     with tempfile.TemporaryDirectory() as tmp:
         inp, out = os.path.join(tmp, "in.txt"), os.path.join(tmp, "out.txt")
         gen.write_input(inp, n, s, d, pat, dl, pl)
-        ref = os.path.join(ROOT, "oracle", "_ref", "gpm-par-ref")
-        mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
         if dl is None and os.path.exists(ref) and os.path.exists(mpirun):
-            try:
-                t0 = time.time()
-                subprocess.run([mpirun, "-np", "2", ref, inp, out], check=True, stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=budget_s)
-                dt = time.time() - t0
-                with open(out, "rb") as f:
-                    count = sum(chunk.count(b"\n") for chunk in iter(lambda: f.read(1 << 24), b""))
-                return {"value": count / dt, "unit": "matches/s", "cores": 2, "kind": "reference",
-                        "sample": sample + ", mpirun -np 2 (1 worker + coordinator)", "matches": count,
-                        "seconds": round(dt, 3)}
-            except Exception as e:  # noqa: BLE001
-                log(f"reference baseline unavailable ({e!r}); timing the oracle port instead")
+            ranks = int(cfg.get("baseline_ranks", 2))
+            binary = ref if ranks == 2 else ref_k
+            dt = run_reference(binary, ranks, inp, out, budget_s) if os.path.exists(binary) else None
+            if dt is not None:
+                count = count_lines(out)
+                base = {"value": count / dt, "unit": "matches/s", "cores": ranks, "kind": "reference",
+                        "sample": sample + f", mpirun -np {ranks} ({ranks - 1} worker(s) + coordinator)",
+                        "matches": count, "seconds": round(dt, 3), "host_cores": total_cores,
+                        "host_cores_usable": usable}
+                legs = {}
+                if ranks != 2:  # also its fastest setting
+                    dt2 = run_reference(ref, 2, inp, out, budget_s)
+                    legs["np2"] = ({"value": count_lines(out) / dt2, "cores": 2, "seconds": round(dt2, 3)}
+                                   if dt2 is not None else {"value": None, "cores": 2, "note": f"DNF in {budget_s} s"})
+                many = forced_many if forced_many >= 3 else min(usable, 64)
+                if many >= 3 and many != ranks and os.path.exists(ref_k) and many_budget_s > 0:
+                    dtk = run_reference(ref_k, many, inp, out, many_budget_s)
+                    legs[f"np{many}"] = ({"value": count_lines(out) / dtk, "cores": many, "seconds": round(dtk, 3)}
+                                         if dtk is not None else
+                                         {"value": None, "cores": many, "note": f"DNF in {many_budget_s} s"})
+                if legs:
+                    base["other_rank_counts"] = legs
+                return base
+            log("reference baseline unavailable; timing the oracle port instead")
         lib = util.oracle_lib()
         t0 = time.time()
         count = lib.oracle_run_file(inp.encode(), out.encode(), 0)
@@ -145,7 +195,33 @@ def cpu_baseline(cfg, budget_s=120):
         if dl is not None:
             sample += " (the reference has no labels: every unlabelled match is enumerated, then filtered)"
         return {"value": count / dt, "unit": "matches/s", "cores": 1, "kind": "port", "sample": sample,
-                "matches": int(count), "seconds": round(dt, 3)}
+                "matches": int(count), "seconds": round(dt, 3), "host_cores": total_cores, "host_cores_usable": usable}
+
+
+# ---- launch -----------------------------------------------------------------
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """Started from a plain shell with --gpus N > 1: run N ranks of this script under torch.distributed.run
+    as a child (nothing in this process has touched a GPU), pass its output through, exit with its code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def kernels_fingerprint():
+    h = hashlib.sha256()
+    for name in ("gpm_kernels.hpp", "gpm_device.hpp", "gpm_hip.hip"):
+        with open(os.path.join(ROOT, "mpi_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -156,29 +232,47 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
                     help="benchmark configuration; 3 (R-MAT scale-24 4-clique) is the headline")
     ap.add_argument("--scale", type=int, default=None, help="override the R-MAT scale of the configuration")
+    ap.add_argument("--ef", type=int, default=None, help="override the R-MAT edge factor of the configuration")
     ap.add_argument("--pattern", default=None, help="override the pattern of the configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-search", action="store_true",
-                    help="skip the untimed search with one chunk in flight (profiling runs: its launches would "
-                         "mix into the per-kernel averages of the timed steps)")
+                    help="skip the untimed searches after the timed region (byte accounting, one chunk in flight); "
+                         "profiling runs: their launches would mix into the per-kernel averages of the timed steps")
     ap.add_argument("--cpu-ranks", type=int, default=0,
-                    help="also time the reference under mpirun -np K (K >= 3) on the twin; off by default, it is slow")
+                    help="rank count of the many-rank leg of the CPU baseline (default min(usable cores, 64))")
+    ap.add_argument("--cpu-many-budget", type=int, default=60, help="seconds the many-rank leg may take (0 = skip)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+    from mpi_amd import binding, dist as gdist, gen
+
     cfg = dict(CONFIGS[args.config])
     cfg["graph"] = dict(cfg["graph"])
-    if args.scale is not None and cfg["graph"]["graph"] == "rmat":
-        cfg["graph"]["scale"] = args.scale
-    if args.pattern is not None:
+    overridden = False
+    if cfg["graph"]["graph"] == "rmat":
+        if args.scale is not None and args.scale != cfg["graph"]["scale"]:
+            cfg["graph"]["scale"] = args.scale
+            overridden = True
+        if args.ef is not None and args.ef != cfg["graph"]["ef"]:
+            cfg["graph"]["ef"] = args.ef
+            overridden = True
+    if args.pattern is not None and args.pattern != cfg["pattern"]:
         cfg["pattern"] = args.pattern
+        overridden = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # GPM_BENCH_BACKEND=gloo is for rehearsing N > 1 on a box with fewer GPUs than ranks
     backend = os.environ.get("GPM_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count()
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -192,7 +286,8 @@ def main():
     n, off, adj = generate(cfg["graph"], dev)
     m_arcs = int(off[-1].item())
     labels = plabels = None
-    if "labels" in cfg and args.pattern is None:
+    labelled = "labels" in cfg and args.pattern is None
+    if labelled:
         labels = gen.vertex_labels(n, cfg["labels"], seed=cfg["graph"]["seed"], device=dev).cpu().numpy()
         plabels = cfg["pattern_labels"]
     off_h, adj_h = off.cpu().numpy(), adj.cpu().numpy()
@@ -212,80 +307,83 @@ def main():
     cursor = gdist.open_cursor(f"bench_{os.environ.get('MASTER_PORT', os.getpid())}")
     matcher.set_cursor(cursor.address)
     matcher.set_chunks(int(os.environ.get("GPM_BENCH_CHUNKS", 64 * world)))
+    # timed steps run without the byte accounting of the clique kernels (an add per adjacent pair inside the
+    # kernels); the bytes, a property of the work, come from one more search after the timed region
+    matcher.set_accounting(False)
+    kinds = binding.KINDS
+    k_ms, k_launches = [0.0] * kinds, [0] * kinds
+    timing = {"on": False}
 
     def step():
         gdist.reset_cursor(cursor)
         local = matcher.findMatches(count_only=True)
-        return gdist.all_reduce_count(local, device=coll_dev)
+        st = matcher.stats()  # HIP-event times of every launch, on the streams the kernels ran on
+        if timing["on"]:
+            for k in range(kinds):
+                k_ms[k] += st.kernel_ms[k]
+                k_launches[k] += st.kernel_launches[k]
+        return gdist.all_reduce_count(local, device=coll_dev), st.ms_total, int(st.chunks[0])
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        timing["on"] = True
 
-    total = 0
-    for _ in range(args.warmup):
-        total = step()
-    fence()
-    t0 = time.perf_counter()
-    kinds = binding.KINDS
-    k_ms, k_bytes, k_launches = [0.0] * kinds, [0] * kinds, [0] * kinds
-    search_ms = 0.0
-    for _ in range(args.steps):
-        total = step()
-        st = matcher.stats()  # HIP-event times of every launch, on the streams the kernels ran on
-        search_ms += st.ms_total
-        for k in range(kinds):
-            k_ms[k] += st.kernel_ms[k]
-            k_bytes[k] += st.kernel_alg_bytes[k]
-            k_launches[k] += st.kernel_launches[k]
-    fence()
-    elapsed = time.perf_counter() - t0
-    busy = [search_ms]  # per-rank time inside the search: the spread shows how well the chunks balance
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        mine = torch.tensor([search_ms], dtype=torch.float64, device=coll_dev)
-        parts = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
-        busy = [float(p.item()) for p in parts]
+    elapsed, total, busy, taken = gdist.timed_steps(step, args.steps, args.warmup, fence, device=coll_dev)
+    timing["on"] = False
     st = matcher.stats()
     sec_per_step = elapsed / max(args.steps, 1)
 
-    # Outside the timed region: one more search with a single chunk in flight, so that every launch has
-    # the GPU to itself.  In the timed steps up to four chunks overlap and a launch's duration includes
-    # the time its workgroups share the compute units with other kernels.
-    alone = None
-    if (rank == 0 and world == 1 and CONFIGS[args.config]["pattern"].startswith("clique") and args.pattern is None
-            and not args.no_extra_search):
-        os.environ["GPM_CLIQUE_INFLIGHT"] = "1"
-        gdist.reset_cursor(cursor)
-        t1 = time.perf_counter()
-        matcher.findMatches(count_only=True)
-        alone_ms = (time.perf_counter() - t1) * 1e3
-        sa = matcher.stats()
-        alone = {"ms_per_step": alone_ms, "kernel_ms": list(sa.kernel_ms), "kernel_alg_bytes": list(sa.kernel_alg_bytes),
-                 "kernel_launches": list(sa.kernel_launches)}
-        del os.environ["GPM_CLIQUE_INFLIGHT"]
+    # Outside the timed region, rank 0 alone (its own cursor word, every chunk): one search with the byte
+    # accounting on -- the merge-model bytes of every kernel family -- and, for the clique path, one with a
+    # single chunk in flight, where every launch has the GPU to itself.
+    k_bytes, alone = [0] * kinds, None
+    if rank == 0 and not args.no_extra_search:
+        matcher.set_cursor(0)
+        matcher.set_accounting(True)
+        check = matcher.findMatches(count_only=True)
+        sb = matcher.stats()
+        k_bytes = [int(x) for x in sb.kernel_alg_bytes]
+        if world == 1 and check != total:
+            raise SystemExit(f"the accounting search counted {check}, the timed steps {total}")
+        matcher.set_accounting(False)
+        if world == 1 and cfg["pattern"].startswith("clique"):
+            os.environ["GPM_CLIQUE_INFLIGHT"] = "1"
+            t1 = time.perf_counter()
+            matcher.findMatches(count_only=True)
+            alone_ms = (time.perf_counter() - t1) * 1e3
+            sa = matcher.stats()
+            alone = {"ms_per_step": alone_ms, "kernel_ms": list(sa.kernel_ms), "kernel_launches": list(sa.kernel_launches)}
+            del os.environ["GPM_CLIQUE_INFLIGHT"]
 
+    rc = 0
     if rank == 0:
-        # the kernel family with the most device time is the one the roofline is quoted on
-        # (among the families that take their operands from HBM: k_clq_count4 works on LDS tiles of rows that
-        # k_clq_build made, its merge-model rate says nothing about HBM)
+        steps = max(args.steps, 1)
         names = [binding.hip_lib().gpm_hip_kernel_name(k).decode() for k in range(kinds)]
+        # The roofline is quoted on the kernel family with the most device time among those that take their
+        # operands from HBM (k_clq_count4 works on LDS tiles of rows that k_clq_build made: its merge-model
+        # rate says nothing about HBM).  Bytes per step are this rank's share of the accounting search's.
         dom = max((k for k in range(kinds) if names[k] != "k_clq_count4"), key=lambda k: k_ms[k])
-        dom_name = binding.hip_lib().gpm_hip_kernel_name(dom).decode()
-        achieved = (k_bytes[dom] / 1e9) / (k_ms[dom] / 1e3) if k_ms[dom] > 0 else 0.0
-        traffic = None
+        share = 1.0  # of the family's launches of a whole search, the part this rank ran per step
+        if world > 1 and not args.no_extra_search:
+            share = (k_launches[dom] / steps) / max(int(sb.kernel_launches[dom]), 1)
+        dom_bytes_per_step = k_bytes[dom] * share
+        achieved = (dom_bytes_per_step * steps / 1e9) / (k_ms[dom] / 1e3) if k_ms[dom] > 0 else 0.0
+        traffic, traffic_note = None, "no committed counter pass"
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch from the committed PMC passes, per kernel family
             with open(tpath) as f:
-                traffic = json.load(f).get(dom_name, {}).get("hbm_bytes_per_launch")
-        families = {binding.hip_lib().gpm_hip_kernel_name(k).decode():
-                    {"ms_per_step": k_ms[k] / max(args.steps, 1), "launches_per_step": k_launches[k] / max(args.steps, 1),
-                     "alg_GB_per_step": k_bytes[k] / 1e9 / max(args.steps, 1)}
+                tj = json.load(f)
+            if tj.get("kernels_fingerprint") == kernels_fingerprint():
+                traffic = tj.get(names[dom], {}).get("hbm_bytes_per_launch")
+                traffic_note = f"rocprofv3 counter passes, {tj.get('source', tpath)}"
+            else:
+                traffic_note = "committed counter pass is of other kernel sources (stale): not reported"
+        families = {names[k]: {"ms_per_step": k_ms[k] / steps, "launches_per_step": k_launches[k] / steps,
+                               "alg_GB_per_search": k_bytes[k] / 1e9}
                     for k in range(kinds) if k_launches[k]}
+        want, want_src = expected_count(args.config, cfg, overridden, labelled)
         line = {
             "metric": "pattern matches found/sec and wall time, R-MAT scale-24 4-clique at 1/2/4/8 GPUs",
             "value": total / sec_per_step,
@@ -305,34 +403,48 @@ def main():
                        "vertices": n, "arcs": m_arcs, "parallelism": f"roots sharded over {world} GPU(s), "
                        "graph replicated, shared chunk cursor"},
             "matches": total,
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "expected_matches": want,
+            "expected_from": want_src,
+            "count_ok": None if want is None else bool(total == want),
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_per_launch": k_bytes[dom] / max(k_launches[dom], 1),
-                         "avg_launch_ms": k_ms[dom] / max(k_launches[dom], 1), "launches": k_launches[dom]},
+                         "traffic_from": traffic_note,
+                         "alg_bytes_per_launch": dom_bytes_per_step * steps / max(k_launches[dom], 1),
+                         "avg_launch_ms": k_ms[dom] / max(k_launches[dom], 1), "launches": k_launches[dom],
+                         "note": "time: HIP events around every launch of the family inside the timed steps; bytes: "
+                                 "merge-model bytes of the same work, summed on the device in one more search"},
             "kernel_families_rank0": families,
             "one_chunk_in_flight": None if alone is None else {
                 "note": "one extra search outside the timed region with launches not overlapping",
-                "ms_per_step": alone["ms_per_step"], "kernel": dom_name,
-                "achieved": (alone["kernel_alg_bytes"][dom] / 1e9) / (alone["kernel_ms"][dom] / 1e3) if alone["kernel_ms"][dom] > 0 else 0.0,
-                "frac": ((alone["kernel_alg_bytes"][dom] / 1e9) / (alone["kernel_ms"][dom] / 1e3) / HBM_PEAK_GBS) if alone["kernel_ms"][dom] > 0 else 0.0,
+                "ms_per_step": alone["ms_per_step"], "kernel": names[dom],
+                "achieved": (k_bytes[dom] / 1e9) / (alone["kernel_ms"][dom] / 1e3) if alone["kernel_ms"][dom] > 0 else 0.0,
+                "frac": ((k_bytes[dom] / 1e9) / (alone["kernel_ms"][dom] / 1e3) / HBM_PEAK_GBS) if alone["kernel_ms"][dom] > 0 else 0.0,
                 "avg_launch_ms": alone["kernel_ms"][dom] / max(alone["kernel_launches"][dom], 1)},
             "partial_matches_per_level_rank0": [int(x) for x in list(st.rows_in)[:plan.n_levels]],
-            "search_ms_per_step_by_rank": [round(b / max(args.steps, 1), 3) for b in busy],
+            "search_ms_per_step_by_rank": [round(b / steps, 3) for b in busy],
+            "chunks_per_step_by_rank": [round(c / steps, 2) for c in taken],
+            "collective": {"backend": backend if world > 1 else None,
+                           "rccl": bool(world > 1 and backend == "nccl"),
+                           "per_step": "2 barriers around the cursor reset + 1 all-reduce of a 64-bit count" if world > 1 else "none"},
+            "host_cores": host_cores()[0],
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg)
-            if args.cpu_ranks >= 3:
-                many = cpu_baseline_many_ranks(cfg, args.cpu_ranks)
-                if many:
-                    line["cpu_baseline_many_ranks"] = many
+            line["cpu_baseline"] = cpu_baseline(cfg, many_budget_s=args.cpu_many_budget, forced_many=args.cpu_ranks)
         print(json.dumps(line), flush=True)
+        if want is not None and total != want:
+            log(f"COUNT MISMATCH: counted {total}, expected {want} ({want_src})")
+            rc = 3
 
     matcher.close()
     if world > 1:
+        flag = torch.tensor([rc], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        rc = int(flag.item())
         dist.barrier()
     cursor.close()
     if world > 1:
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -111,3 +111,35 @@ def sharded_search(search_chunks, cursor: SharedCursor, count_only: bool, device
     if count_only:
         return all_reduce_count(local, device)
     return all_gather_matches(local, device)
+
+
+def timed_steps(step, steps: int, warmup: int, fence, device="cpu"):
+    """The benchmark's measuring protocol, shared by every rank: `warmup` untimed steps, then exactly
+    `steps` steps bracketed by `fence()` (barrier + device synchronisation) on both sides.  Returns
+    (seconds -- the maximum over ranks --, the last step's result, per-rank lists gathered on every rank of
+    what `step` reported as busy milliseconds and chunks taken).  `step()` returns (result, busy_ms, chunks)."""
+    import time
+    result = None
+    for _ in range(warmup):
+        result, _, _ = step()
+    fence()
+    t0 = time.perf_counter()
+    busy_ms, chunks = 0.0, 0
+    for _ in range(steps):
+        result, b, c = step()
+        busy_ms += b
+        chunks += c
+    fence()
+    elapsed = time.perf_counter() - t0
+    busy, taken = [busy_ms], [chunks]
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        world = dist.get_world_size()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        mine = torch.tensor([busy_ms, float(chunks)], dtype=torch.float64, device=device)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        busy = [float(p[0].item()) for p in parts]
+        taken = [int(p[1].item()) for p in parts]
+    return elapsed, result, busy, taken

@@ -25,6 +25,17 @@ FAMILIES = {"k_tail": ("k_tail", "k_leaf_pair"), "k_extend": ("k_extend",), "k_c
             "k_clq_build": ("k_clq_build",), "k_clq_count4": ("k_clq_count4",), "k_cycle4": ("k_cycle4_light", "k_cycle4_heavy")}
 
 
+def fingerprint():
+    """Hash of the kernel sources the counters were collected from; bench.py reports the traffic only
+    while the sources still hash to it."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("gpm_kernels.hpp", "gpm_device.hpp", "gpm_hip.hip"):
+        with open(os.path.join("mpi_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def short(name):
     return name.split("(")[0].replace("void ", "").strip()
 
@@ -88,7 +99,7 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
 #    bench.py's roofline.achieved; the counters cover every search of the profiled run
 traffic = {"note": "read bytes = 2 x FETCH_SIZE KiB (gfx950 correction, calibrated with scripts/calib_fetch), "
                    "write bytes = WRITE_SIZE KiB; sums over the whole profiled run (warm-up and timed steps)",
-           "source": f"profiles/{tag}_pmc_summary.json"}
+           "source": f"profiles/{tag}_pmc_summary.json", "kernels_fingerprint": fingerprint()}
 for fam, prefixes in FAMILIES.items():
     part = [v for k, v in summary.items() if k.startswith(prefixes)]
     calls = sum(v["calls"] for v in part)

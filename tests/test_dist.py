@@ -71,3 +71,75 @@ def test_two_ranks_share_the_work_and_agree(tmp_path):
         rows = np.load(tmp_path / f"r{r}.npy")
         assert sorted(map(tuple, rows.tolist())) == sorted(map(tuple, want_rows.tolist()))
     assert sorted(seen) == list(range((n + 15) // 16)), "every chunk is taken exactly once"
+
+
+def _timing_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import time
+    import torch.distributed as dist
+    from mpi_amd import dist as gdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cur = gdist.open_cursor(f"timing_{port}")
+    host = __import__("mpi_amd.binding", fromlist=["x"]).host_lib()
+    host.claimChunk.restype = ctypes.c_uint64
+    host.claimChunk.argtypes = [ctypes.c_void_p]
+    calls = []
+
+    def step():
+        gdist.reset_cursor(cur)
+        mine = 0
+        while host.claimChunk(cur.address) < 10:  # ten chunks shared by the ranks
+            mine += 1
+            time.sleep(0.01 * (rank + 1))
+        calls.append(mine)
+        return gdist.all_reduce_count(mine), 10.0 * (rank + 1), mine
+
+    fenced = []
+
+    def fence():
+        dist.barrier()
+        fenced.append(len(calls))
+
+    elapsed, result, busy, taken = gdist.timed_steps(step, steps=3, warmup=2, fence=fence)
+    with open(os.path.join(out_dir, f"t{rank}.txt"), "w") as f:
+        f.write(repr({"elapsed": elapsed, "result": result, "busy": busy, "taken": taken, "fenced": fenced,
+                      "calls": calls}))
+    dist.barrier()
+    cur.close()
+    dist.destroy_process_group()
+
+
+def test_the_benchmark_protocol_on_two_ranks(tmp_path):
+    """bench.py's measuring loop (mpi_amd.dist.timed_steps): untimed warm-up, K steps between two fences,
+    the maximum over ranks as the time, per-rank busy time and chunk counts gathered on every rank; in
+    every step the two ranks take all ten chunks between them exactly once."""
+    world = 2
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_timing_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [eval(open(tmp_path / f"t{r}.txt").read()) for r in range(world)]
+    assert got[0]["elapsed"] == got[1]["elapsed"] > 0          # the maximum, on every rank
+    assert got[0]["result"] == got[1]["result"] == 10          # all-reduced count of the last step
+    assert got[0]["busy"] == got[1]["busy"] == [30.0, 60.0]    # 3 timed steps x 10 ms and 20 ms
+    assert got[0]["taken"] == got[1]["taken"] and sum(got[0]["taken"]) == 30
+    for r in range(world):
+        assert got[r]["fenced"] == [2, 5]                      # fences after the warm-up and after the steps
+        assert len(got[r]["calls"]) == 5
+    for k in range(5):
+        assert got[0]["calls"][k] + got[1]["calls"][k] == 10
+
+
+def test_bench_launches_its_own_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` from a plain shell starts two ranks itself; on a machine without a GPU
+    they must stop with an error (no CPU stand-in), not hang and not print a result."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU; the GPU suite runs the real two-rank benchmark")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["GPM_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "10", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout

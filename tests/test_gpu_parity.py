@@ -760,3 +760,24 @@ def test_bad_arguments_are_rejected():
     with pytest.raises(binding.GpmError):
         m.findMatches()  # nothing uploaded
     m.close()
+
+
+def test_bench_with_two_ranks_from_a_plain_shell(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: the script starts its two ranks itself (both on
+    this GPU, gloo for the collectives), they share the chunk cursor, and the one JSON line carries the
+    count of the captured vector for this size, which the script checked itself."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["GPM_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--scale", "12", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    spec = next(g for g in LARGE if g["name"] == "rmat12_ef16_clique4")
+    assert out["n_gpus"] == 2 and out["matches"] == spec["count"] and out["count_ok"] is True
+    assert len(out["search_ms_per_step_by_rank"]) == 2 and len(out["chunks_per_step_by_rank"]) == 2
+    assert sum(out["chunks_per_step_by_rank"]) >= 2  # every chunk of a step taken by one of the two ranks
+    assert out["roofline"]["frac"] > 0 and out["scaling"] == "strong"
