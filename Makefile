@@ -2,6 +2,7 @@
 # program (same target name as the reference's Makefile: gpm-par.exe).
 #
 #   make            libgpm_hip.so, libgpm_host.so, gpm-par.exe  (in mpi_amd/lib, repo root)
+#   make sanitize   host C code and the oracle under ASan + UBSan (mpi_amd/lib/san/)
 #   make oracle     CPU oracle (test infrastructure) and, if possible, the reference build
 HIPCC   ?= /opt/rocm/bin/hipcc
 CC      ?= gcc
@@ -25,6 +26,23 @@ $(LIBDIR)/libgpm_host.so: $(HOST_SRC) $(HOST_HDR)
 gpm-par.exe: mpi_amd/host/gpm-par.c $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libgpm_hip.so
 	$(CC) $(CFLAGS) -o $@ mpi_amd/host/gpm-par.c $(HOST_SRC) -L$(LIBDIR) -lgpm_hip -lpthread -Wl,-rpath,'$$ORIGIN/$(LIBDIR)'
 
+# The host-side C (parser, threaded loader, CSR cache, planner) and the oracle under AddressSanitizer
+# and UndefinedBehaviorSanitizer, next to a plain build of the same checker; CPU code only.
+SANFLAGS ?= -O1 -g -std=c99 -Wall -Wextra -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer
+sanitize: $(LIBDIR)/san/host_check $(LIBDIR)/san/host_check_plain $(LIBDIR)/san/gpm_oracle
+
+$(LIBDIR)/san/host_check: mpi_amd/host/host_check.c $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p $(LIBDIR)/san
+	$(CC) $(SANFLAGS) -o $@ mpi_amd/host/host_check.c $(HOST_SRC) -lpthread
+
+$(LIBDIR)/san/host_check_plain: mpi_amd/host/host_check.c $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p $(LIBDIR)/san
+	$(CC) -O2 -std=c99 -Wall -Wextra -o $@ mpi_amd/host/host_check.c $(HOST_SRC) -lpthread
+
+$(LIBDIR)/san/gpm_oracle: oracle/gpm_oracle.c oracle/gpm_oracle.h
+	@mkdir -p $(LIBDIR)/san
+	$(CC) $(SANFLAGS) -DORACLE_MAIN -o $@ oracle/gpm_oracle.c
+
 oracle:
 	$(MAKE) -C oracle all
 	-$(MAKE) -C oracle ref
@@ -32,4 +50,4 @@ oracle:
 clean:
 	rm -rf $(LIBDIR) gpm-par.exe
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean sanitize

@@ -259,9 +259,13 @@ static int cachePath(const char *input, char *out, size_t outLen) {
     if (!on || !*on || strcmp(on, "0") == 0) return 0;
     const char *dir = getenv("GPM_CSR_CACHE_DIR");
     if (dir && *dir) {
+        /* keyed on the whole path as given (two inputs with one file name must not share a side-car):
+         * file name plus a hash of the path */
         const char *base = strrchr(input, '/');
         base = base ? base + 1 : input;
-        return snprintf(out, outLen, "%s/%s.gpmcsr", dir, base) < (int)outLen;
+        uint64_t h = 1469598103934665603ull; /* FNV-1a */
+        for (const char *c = input; *c; ++c) h = (h ^ (uint8_t)*c) * 1099511628211ull;
+        return snprintf(out, outLen, "%s/%s.%016llx.gpmcsr", dir, base, (unsigned long long)h) < (int)outLen;
     }
     return snprintf(out, outLen, "%s.gpmcsr", input) < (int)outLen;
 }
@@ -284,7 +288,8 @@ static Graph *cacheLoad(const char *path, const struct stat *in, int64_t *restOf
     Graph *g = NULL;
     if (fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "GPMCSR1", 8) == 0 && h.inputSize == (int64_t)in->st_size &&
         h.inputMtimeSec == (int64_t)in->st_mtim.tv_sec && h.inputMtimeNsec == (int64_t)in->st_mtim.tv_nsec &&
-        h.nodesCount >= 0 && h.nodesCount < INT32_MAX && h.edgesCount >= 0 && h.restOffset <= h.inputSize) {
+        h.nodesCount >= 0 && h.nodesCount < INT32_MAX && h.edgesCount >= 0 && h.restOffset >= 0 &&
+        h.restOffset <= h.inputSize && h.restLine >= 0) {
         size_t n = (size_t)h.nodesCount, m = (size_t)h.edgesCount;
         g = safeCalloc(1, sizeof *g);
         g->nodesCount = (int32_t)n;
@@ -302,7 +307,14 @@ static Graph *cacheLoad(const char *path, const struct stat *in, int64_t *restOf
         } else if (ok) {
             ok = readAll(f, g->inOffsets, (n + 1) * sizeof(int64_t)) == 0 && readAll(f, g->inEdges, m * sizeof(int32_t)) == 0;
         }
-        ok = ok && g->outOffsets[0] == 0 && g->outOffsets[n] == (int64_t)m && g->inOffsets[n] == (int64_t)m;
+        ok = ok && g->outOffsets[0] == 0 && g->outOffsets[n] == (int64_t)m && g->inOffsets[0] == 0 &&
+             g->inOffsets[n] == (int64_t)m;
+        /* a side-car that was truncated, edited or written by something else must not reach the CSR
+         * consumers unchecked: offsets ascend, ids are vertices (what the text parser guarantees) */
+        for (size_t v = 0; ok && v < n; ++v)
+            ok = g->outOffsets[v] <= g->outOffsets[v + 1] && g->inOffsets[v] <= g->inOffsets[v + 1];
+        for (size_t e = 0; ok && e < m; ++e)
+            ok = (uint32_t)g->outEdges[e] < (uint32_t)n && (uint32_t)g->inEdges[e] < (uint32_t)n;
         if (!ok) {
             freeGraph(g);
             g = NULL;
@@ -395,10 +407,15 @@ static int parseInput(const char *buf, int64_t len, Graph *cached, int64_t restO
         return -1;
     }
     /* Optional trailer, ignored by the reference (it stops reading at the
-     * blank line that ends the pattern): the word "labels", then one label
-     * per data vertex and one per pattern vertex. */
+     * blank line that ends the pattern): a line that holds the single word
+     * "labels", then one label per data vertex and one per pattern vertex.
+     * Any other text after the pattern is ignored as the reference ignores
+     * it, and GPM_LABELS=0 makes this program ignore a labels trailer too. */
     skipSpace(&s);
-    if (s.end - s.p >= 6 && memcmp(s.p, "labels", 6) == 0) {
+    const char *labelsOff = getenv("GPM_LABELS");
+    int wantLabels = !(labelsOff && strcmp(labelsOff, "0") == 0);
+    if (wantLabels && s.end - s.p >= 6 && memcmp(s.p, "labels", 6) == 0 &&
+        (s.end - s.p == 6 || s.p[6] == '\n' || s.p[6] == '\r' || s.p[6] == ' ' || s.p[6] == '\t')) {
         s.p += 6;
         g->labels = safeMalloc((size_t)g->nodesCount);
         int ok = 1;

@@ -183,8 +183,9 @@ def test_csr_cache_gives_the_same_graph(name, tmp_path, monkeypatch):
     monkeypatch.setenv("GPM_CSR_CACHE", "1")
     monkeypatch.setenv("GPM_CSR_CACHE_DIR", str(cache_dir))
     stored = _read_both_ways(str(p), monkeypatch)[0]           # parses and stores
-    side_car = cache_dir / "in.txt.gpmcsr"
-    assert side_car.exists()
+    cars = list(cache_dir.glob("in.txt.*.gpmcsr"))  # file name + hash of the input's path
+    assert len(cars) == 1
+    side_car = cars[0]
     stamp = side_car.stat().st_mtime_ns
     loaded = _read_both_ways(str(p), monkeypatch)[0]           # loads
     assert side_car.stat().st_mtime_ns == stamp                # not rewritten: it was used
@@ -197,6 +198,19 @@ def test_csr_cache_gives_the_same_graph(name, tmp_path, monkeypatch):
     monkeypatch.setenv("GPM_CSR_CACHE", "1")
     got = _read_both_ways(str(p), monkeypatch)[0]
     assert _same(want, got) and not _same(first, got)
+    # a side-car whose contents are damaged (ids out of range, same size and header) is rejected, not used
+    blob = bytearray(side_car.read_bytes())
+    blob[-4:] = (2 ** 31 - 1).to_bytes(4, "little")
+    side_car.write_bytes(bytes(blob))
+    again = _read_both_ways(str(p), monkeypatch)[0]
+    assert _same(want, again)
+    # the same file name in another directory gets a side-car of its own
+    other_dir = tmp_path / "elsewhere"
+    other_dir.mkdir()
+    q = other_dir / "in.txt"
+    q.write_text(text)
+    there = _read_both_ways(str(q), monkeypatch)[0]
+    assert _same(first, there) and len(list(cache_dir.glob("in.txt.*.gpmcsr"))) == 2
 
 
 def test_symmetric_and_simple_flags(tmp_path):
@@ -363,3 +377,74 @@ def test_cli_missing_input(tmp_path):
 def test_cli_nonzero_mpi_ranks_exit_quietly(tmp_path):
     r = run_exe([], env={"PMI_RANK": "1"})
     assert r.returncode == 0 and r.stderr == "" and r.stdout == ""
+
+
+def test_text_after_the_pattern_is_ignored_unless_it_is_a_labels_trailer(tmp_path, monkeypatch):
+    """The reference stops reading at the blank line that ends the pattern.  Only a line holding the
+    single word `labels` starts the trailer; GPM_LABELS=0 ignores even that."""
+    base = "3\n1 2\n2\n3\n2 1\n3\n\n2\n1 1\n2\n\n"
+    for tail, labelled in (("labelsfoo 1 2\n", False), ("labels_are_nice\n", False), ("7 7\n", False),
+                           ("labels\n0\n1\n0\n0\n1\n", True)):
+        p = tmp_path / "x.in"
+        p.write_text(base + tail)
+        data, pat = binding.readGraph(str(p))
+        assert (data["labels"] is not None) == labelled, tail
+        binding.host_lib().freePattern(pat)
+    monkeypatch.setenv("GPM_LABELS", "0")
+    data, pat = binding.readGraph(str(p))
+    assert data["labels"] is None
+    binding.host_lib().freePattern(pat)
+    monkeypatch.delenv("GPM_LABELS")
+    p.write_text(base + "labels\n0\n1\n")  # too few labels
+    with pytest.raises(binding.GpmError):
+        binding.readGraph(str(p))
+
+
+def test_host_code_and_oracle_under_sanitizers(tmp_path):
+    """`make sanitize`: parser, threaded loader, CSR cache, planner (host_check) and the oracle built with
+    AddressSanitizer + UndefinedBehaviorSanitizer run over the hand-written cases, generated inputs and
+    malformed inputs: no sanitizer report, the same digests as the plain build, the golden outputs."""
+    import subprocess
+    subprocess.run(["make", "-C", util.ROOT, "sanitize"], check=True, stdout=subprocess.DEVNULL)
+    san = os.path.join(util.ROOT, "mpi_amd", "lib", "san")
+    files = [util.small_paths(n)[0] for n in util.small_cases()]
+    for name in ("rand40_dir_tree5_dir", "rmat8_house", "plaw9_tree5_labelled4", "rmat10_clique4", "rand9_sym_clique4",
+                 "skew8_k6_minus_e"):
+        spec = next(g for g in util.golden_specs() if g["name"] == name)
+        f = tmp_path / (name + ".in")
+        f.write_text(util.build_input(spec)[0])
+        files.append(str(f))
+    body = "".join(f"{v} 2\n{v % 50 + 1}\n{(v + 7) % 50 + 1}\n" for v in range(1, 51))
+    odd = {
+        "crlf": ("50\n" + body + "\n2\n1 1\n2\n").replace("\n", "\r\n"),
+        "degree_too_large": "50\n" + body.replace("3 2\n", "3 3\n", 1) + "\n2\n1 1\n2\n",
+        "id_out_of_range": "50\n" + body.replace("\n9\n", "\n99\n", 1) + "\n2\n1 1\n2\n",
+        "no_blank_line": "50\n" + body,
+        "long_line": "50\n" + body.replace("\n9\n", "\n" + "0" * 70 + "9\n", 1) + "\n2\n1 1\n2\n",
+        "truncated": "3\n1 2\n2\n",
+        "empty": "",
+        "pattern_too_large": "3\n1 1\n2\n\n11\n1 1\n2\n",
+        "bad_labels": "3\n1 1\n2\n\n2\n1 1\n2\n\nlabels\n1\n",
+        "disconnected_pattern": "3\n1 1\n2\n\n3\n1 1\n2\n",
+    }
+    for name, text in odd.items():
+        f = tmp_path / (name + ".in")
+        f.write_bytes(text.encode())
+        files.append(str(f))
+    env = dict(os.environ)
+    env.update({"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "halt_on_error=1",
+                "GPM_LOAD_MIN_BYTES": "0"})
+    for threads, cache in (("1", "0"), ("5", "0"), ("5", "1"), ("5", "1")):  # the last run loads the side-cars
+        env.update({"GPM_LOAD_THREADS": threads, "GPM_CSR_CACHE": cache, "GPM_CSR_CACHE_DIR": str(tmp_path)})
+        a = subprocess.run([os.path.join(san, "host_check")] + files, capture_output=True, text=True, env=env, timeout=600)
+        b = subprocess.run([os.path.join(san, "host_check_plain")] + files, capture_output=True, text=True, env=env,
+                           timeout=600)
+        assert a.returncode == 0 and a.stderr == "", a.stderr[-3000:]
+        assert a.stdout == b.stdout and a.stdout.count("\n") == len(files)
+    for name in util.small_cases():
+        inp, out = util.small_paths(name)
+        got = tmp_path / "o.txt"
+        r = subprocess.run([os.path.join(san, "gpm_oracle"), inp, str(got)], capture_output=True, text=True, env=env,
+                           timeout=600)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+        assert got.read_bytes() == open(out, "rb").read()
