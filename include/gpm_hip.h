@@ -19,7 +19,12 @@
  *   - the library never calls back into host code from device threads; the
  *     row sink of gpm_hip_search() runs on the calling host thread;
  *   - one context may drive several GPUs of one node; calls on one context
- *     must not overlap.
+ *     must not overlap.  In output mode the match lists of all GPUs are
+ *     gathered on GPU 0 in rounds -- RCCL all-gather of the row counts and of
+ *     the lists padded to the longest, or peer copies when the context has no
+ *     communicators -- and GPU 0's copy goes to the sink (replaces the message
+ *     per match to rank 0, reference: src/gpm-par.c:181, :608-621).
+ *     GPM_GATHER=host makes every GPU hand its own rows to the host instead.
  */
 #ifndef GPM_HIP_H_
 #define GPM_HIP_H_
@@ -127,6 +132,9 @@ typedef struct {
     double   kernel_ms[GPM_KERNEL_KINDS];
     uint64_t kernel_launches[GPM_KERNEL_KINDS];
     uint64_t kernel_alg_bytes[GPM_KERNEL_KINDS];
+    /* output mode on several GPUs: gather rounds run (meetings of all workers) and canonical rows that
+     * reached the writer through GPU 0 (RCCL all-gather, or peer copies without communicators) */
+    uint64_t gather_rounds, gathered_rows;
 } gpm_stats;
 
 /* Row sink: called on the calling host thread with `nrows` complete matches,

@@ -57,7 +57,8 @@ class gpm_stats(ctypes.Structure):
                 ("tail_launches", ctypes.c_uint64), ("extend_launches", ctypes.c_uint64),
                 ("chunks", ctypes.c_uint64 * 8),
                 ("kernel_ms", ctypes.c_double * KINDS), ("kernel_launches", ctypes.c_uint64 * KINDS),
-                ("kernel_alg_bytes", ctypes.c_uint64 * KINDS)]
+                ("kernel_alg_bytes", ctypes.c_uint64 * KINDS),
+                ("gather_rounds", ctypes.c_uint64), ("gathered_rows", ctypes.c_uint64)]
 
 
 PLAN_SYMMETRIC_DATA, PLAN_BREAK_SYMMETRY, PLAN_DEGREE_FILTER, PLAN_REFERENCE_ORDER = 1, 2, 4, 8

@@ -156,6 +156,11 @@ struct DevState {
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     int32_t *emit = nullptr, *emit_host = nullptr;
+    // output mode on several GPUs: rows wait here for the next gather round (see gather_round)
+    int32_t *ag_send = nullptr, *ag_recv = nullptr;  // cap_emit rows; ngpus x cap_emit rows
+    unsigned long long *ag_counts = nullptr;         // [0] this GPU's row count, [1, 1 + ngpus) everybody's
+    uint64_t ag_rows = 0;                            // rows waiting in ag_send
+    int index = 0;                                   // position of this device in the context
     // text output: automorphism table, line offsets, text on the device and two pinned host buffers
     int8_t *aut_dev = nullptr;
     int64_t *line_off = nullptr;
@@ -223,6 +228,12 @@ struct gpm_ctx {
     bool cycle4 = false;  // the plan is the 4-cycle with all 8 automorphisms folded
     bool use_cycle4 = true;
     bool accounting = true;  // sum merge-model bytes in the clique kernels (gpm_hip_set_accounting)
+    // tuning knobs, read from the environment once when the context is made
+    int64_t fuse3_group = 8, twin_group = 1;
+    bool fuse3_wave = true, fuse3_mid = true, trace = false;
+    int clique_max_d_env = -1;   // GPM_CLIQUE_MAX_D, -1 = unset
+    int clique_small_max = 256;  // GPM_CLIQUE_SMALL_MAX
+    int64_t cyc_heavy_block = 2048, cyc_span = (int64_t)1 << 18;
     int64_t cyc_heavy_thr = 0;             // two-paths from which a root is cut into spans (k_cycle4_heavy)
     std::vector<int64_t> cyc_heavy_roots;  // root indices at or above the threshold, ascending
     std::vector<int64_t> cyc_heavy_paths;  // their two-path counts
@@ -241,6 +252,16 @@ struct gpm_ctx {
     std::atomic<bool> stop{false};
     gpm_stats stats{};
     std::vector<void *> comms;  // one RCCL communicator per GPU (several GPUs, or GPM_FORCE_RCCL=1)
+    // gather rounds of an output-mode search on several GPUs (see gather_round)
+    bool gather_on_device = true;     // GPM_GATHER=host: every worker hands its own rows to the host queue instead
+    struct {
+        int arrived = 0, finished = 0;
+        uint64_t generation = 0;
+        std::atomic<bool> requested{false};
+        uint64_t rows[2][8] = {};     // per round parity: rows every worker brings
+        bool last[2] = {false, false};  // per round parity: every worker had finished when the round formed
+        uint64_t rounds = 0, gathered_rows = 0;
+    } gs;
     DevState na;                      // view of devs[0] whose search buffers lie in gpm_scratch
     unsigned char *scratch0 = nullptr;  // devs[0]'s copy of gpm_scratch
 };
@@ -260,12 +281,13 @@ struct Rccl {
     int (*CommDestroy)(void *comm) = nullptr;
     int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm,
                      hipStream_t stream) = nullptr;
+    int (*AllGather)(const void *send, void *recv, size_t sendcount, int dtype, void *comm, hipStream_t stream) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool ok() const { return lib != nullptr; }
 };
-enum { RCCL_SUM = 0, RCCL_UINT64 = 5 };  // ncclSum, ncclUint64 (rccl.h)
+enum { RCCL_SUM = 0, RCCL_INT32 = 2, RCCL_UINT64 = 5 };  // ncclSum, ncclInt32, ncclUint64 (rccl.h)
 
 static Rccl &rccl() {
     static Rccl r;
@@ -280,10 +302,12 @@ static Rccl &rccl() {
         t.CommInitAll = (decltype(t.CommInitAll))dlsym(lib, "ncclCommInitAll");
         t.CommDestroy = (decltype(t.CommDestroy))dlsym(lib, "ncclCommDestroy");
         t.AllReduce = (decltype(t.AllReduce))dlsym(lib, "ncclAllReduce");
+        t.AllGather = (decltype(t.AllGather))dlsym(lib, "ncclAllGather");
         t.GroupStart = (decltype(t.GroupStart))dlsym(lib, "ncclGroupStart");
         t.GroupEnd = (decltype(t.GroupEnd))dlsym(lib, "ncclGroupEnd");
         t.GetErrorString = (decltype(t.GetErrorString))dlsym(lib, "ncclGetErrorString");
-        if (t.CommInitAll && t.CommDestroy && t.AllReduce && t.GroupStart && t.GroupEnd && t.GetErrorString) {
+        if (t.CommInitAll && t.CommDestroy && t.AllReduce && t.AllGather && t.GroupStart && t.GroupEnd &&
+            t.GetErrorString) {
             t.lib = lib;
             r = t;
         }
@@ -329,6 +353,26 @@ static void dev_free(void *p) {
 static void host_free(void *p) {
     if (p) (void)hipHostFree(p);
 }
+
+// Device memory that lives for one call: released on every return path, error returns included.
+struct Scratch {
+    void *p = nullptr;
+    Scratch() = default;
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    ~Scratch() { dev_free(p); }
+    hipError_t alloc(size_t bytes) {
+        dev_free(p);
+        p = nullptr;
+        return hipMalloc(&p, bytes ? bytes : 8);
+    }
+    void release() {
+        dev_free(p);
+        p = nullptr;
+    }
+    template <class T>
+    T *as() const { return static_cast<T *>(p); }
+};
 
 static void free_graph(DevState &d) {
     (void)hipSetDevice(d.dev);
@@ -408,6 +452,11 @@ static void free_buffers(DevState &d) {
     d.text_lines_cap = 0;
     dev_free(d.emit);
     host_free(d.emit_host);
+    dev_free(d.ag_send);
+    dev_free(d.ag_recv);
+    dev_free(d.ag_counts);
+    d.ag_send = d.ag_recv = nullptr;
+    d.ag_counts = nullptr;
     d.scan_tmp = nullptr;
     d.emit = nullptr;
     d.emit_host = nullptr;
@@ -449,6 +498,7 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->devs.resize((size_t)ngpus);
     for (int i = 0; i < ngpus; ++i) {
         DevState &d = ctx->devs[(size_t)i];
+        d.index = i;
         d.dev = devices ? devices[i] : i;
         if (d.dev < 0 || d.dev >= have) {
             gpm_hip_destroy(ctx);
@@ -486,6 +536,19 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->use_cycle4 = env_i64("GPM_NO_CYCLE4", 0) == 0;
     ctx->cyc_heavy_thr = std::max<int64_t>(1, env_i64("GPM_CYCLE4_HEAVY", (int64_t)1 << 16));
     ctx->accounting = env_i64("GPM_ACCOUNTING", 1) != 0;
+    {
+        const char *gm = getenv("GPM_GATHER");
+        ctx->gather_on_device = !(gm && strcmp(gm, "host") == 0);
+    }
+    ctx->fuse3_group = env_i64("GPM_FUSE3_GROUP", 8);
+    ctx->fuse3_wave = env_i64("GPM_FUSE3_WAVE", 1) != 0;
+    ctx->fuse3_mid = env_i64("GPM_FUSE3_MID", 1) != 0;
+    ctx->twin_group = env_i64("GPM_TWIN_GROUP", 1);
+    ctx->trace = getenv("GPM_TRACE") != nullptr;
+    ctx->clique_max_d_env = (int)env_i64("GPM_CLIQUE_MAX_D", -1);
+    ctx->clique_small_max = (int)std::min<int64_t>(256, std::max<int64_t>(4, env_i64("GPM_CLIQUE_SMALL_MAX", 256)));
+    ctx->cyc_heavy_block = std::max<int64_t>(256, env_i64("GPM_CYC_HEAVY_BLOCK", 2048)) / 256 * 256;
+    ctx->cyc_span = std::max<int64_t>(1, env_i64("GPM_CYC_SPAN", (int64_t)1 << 18) / ctx->cyc_heavy_block) * ctx->cyc_heavy_block;
     for (auto &d : ctx->devs) {
         d.clq_probe_bias = (int)env_i64("GPM_CLIQUE_PROBE_BIAS", 0);
         d.count4_wide = env_i64("GPM_COUNT4_WAVES", 16) >= 16;
@@ -530,46 +593,39 @@ static int rebuild_direction(DevState &d, int dir, const int64_t *old_off, const
                              const int32_t *rank, uint32_t *flags) {
     const int32_t n = d.n;
     hipStream_t s = d.stream;
-    int64_t *new_deg = nullptr;
+    Scratch new_deg, rank_tmp, tmp, keys, keys2;
     HIP_TRY(hipMalloc(&d.off[dir], ((size_t)n + 1) * sizeof(int64_t)));
     HIP_TRY(hipMalloc(&d.mid[dir], ((size_t)n + 1) * sizeof(int64_t)));
     HIP_TRY(hipMalloc(&d.adj[dir], ((size_t)m + 1) * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&new_deg, ((size_t)n + 1) * sizeof(int64_t)));
-    int32_t *rank_tmp = nullptr;  // k_scatter_rank writes rank again; harmless, keeps one kernel
-    HIP_TRY(hipMalloc(&rank_tmp, ((size_t)n + 1) * sizeof(int32_t)));
-    if (n > 0) k_scatter_rank<<<grid_for(n), 256, 0, s>>>(n, d.perm, rank_tmp, old_off, new_deg);
+    HIP_TRY(new_deg.alloc(((size_t)n + 1) * sizeof(int64_t)));
+    HIP_TRY(rank_tmp.alloc(((size_t)n + 1) * sizeof(int32_t)));  // k_scatter_rank writes rank again; harmless, keeps one kernel
+    if (n > 0) k_scatter_rank<<<grid_for(n), 256, 0, s>>>(n, d.perm, rank_tmp.as<int32_t>(), old_off, new_deg.as<int64_t>());
     HIP_TRY(hipMemsetAsync(d.off[dir], 0, sizeof(int64_t), s));
     size_t tmp_bytes = 0;
-    void *tmp = nullptr;
     if (n > 0) {
-        HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, new_deg, d.off[dir] + 1, (size_t)n,
+        HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, new_deg.as<int64_t>(), d.off[dir] + 1, (size_t)n,
                                         rocprim::plus<int64_t>(), s));
-        HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-        HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, new_deg, d.off[dir] + 1, (size_t)n, rocprim::plus<int64_t>(),
-                                        s));
+        HIP_TRY(tmp.alloc(tmp_bytes));
+        HIP_TRY(rocprim::inclusive_scan(tmp.p, tmp_bytes, new_deg.as<int64_t>(), d.off[dir] + 1, (size_t)n,
+                                        rocprim::plus<int64_t>(), s));
         HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipFree(tmp));
     }
     if (m > 0) {
-        uint64_t *keys = nullptr, *keys2 = nullptr;
-        HIP_TRY(hipMalloc(&keys, (size_t)m * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc(&keys2, (size_t)m * sizeof(uint64_t)));
-        k_arc_keys<<<grid_for(m), 256, 0, s>>>(n, m, old_off, old_adj, rank, keys);
+        HIP_TRY(keys.alloc((size_t)m * sizeof(uint64_t)));
+        HIP_TRY(keys2.alloc((size_t)m * sizeof(uint64_t)));
+        k_arc_keys<<<grid_for(m), 256, 0, s>>>(n, m, old_off, old_adj, rank, keys.as<uint64_t>());
         unsigned end_bit = 32u + (unsigned)bits_for(n);
         tmp_bytes = 0;
-        HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, keys2, (size_t)m, 0u, end_bit, s));
-        HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-        HIP_TRY(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, keys2, (size_t)m, 0u, end_bit, s));
-        k_keys_to_adj<<<grid_for(m), 256, 0, s>>>(m, keys2, d.adj[dir]);
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), (size_t)m, 0u,
+                                         end_bit, s));
+        HIP_TRY(tmp.alloc(tmp_bytes));
+        HIP_TRY(rocprim::radix_sort_keys(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), (size_t)m, 0u,
+                                         end_bit, s));
+        k_keys_to_adj<<<grid_for(m), 256, 0, s>>>(m, keys2.as<uint64_t>(), d.adj[dir]);
         HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipFree(tmp));
-        HIP_TRY(hipFree(keys));
-        HIP_TRY(hipFree(keys2));
     }
     if (n > 0) k_mid_and_flags<<<grid_for(n), 256, 0, s>>>(n, d.off[dir], d.adj[dir], d.mid[dir], flags);
     HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipFree(new_deg));
-    HIP_TRY(hipFree(rank_tmp));
     d.m[dir] = m;
     return GPM_OK;
 }
@@ -582,59 +638,53 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
     d.n = n;
     const int64_t m_out = out_off[n];
     const int64_t m_in = in_off ? in_off[n] : 0;
-    int64_t *o_off[2] = {nullptr, nullptr};
-    int32_t *o_adj[2] = {nullptr, nullptr};
-    uint32_t *flags = nullptr;
-    HIP_TRY(hipMalloc(&flags, sizeof(uint32_t)));
+    Scratch o_off[2], o_adj[2], flags_buf;
+    HIP_TRY(flags_buf.alloc(sizeof(uint32_t)));
+    uint32_t *flags = flags_buf.as<uint32_t>();
     HIP_TRY(hipMemsetAsync(flags, 0, sizeof(uint32_t), s));
     const int ndir = in_off ? 2 : 1;
     for (int dir = 0; dir < ndir; ++dir) {
         const int64_t *ho = dir ? in_off : out_off;
         const int32_t *ha = dir ? in_adj : out_adj;
         int64_t m = dir ? m_in : m_out;
-        HIP_TRY(hipMalloc(&o_off[dir], ((size_t)n + 1) * sizeof(int64_t)));
-        HIP_TRY(hipMalloc(&o_adj[dir], ((size_t)m + 1) * sizeof(int32_t)));
-        HIP_TRY(hipMemcpyAsync(o_off[dir], ho, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
-        if (m > 0) HIP_TRY(hipMemcpyAsync(o_adj[dir], ha, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        k_validate_off<<<grid_for((int64_t)n + 1), 256, 0, s>>>(n, m, o_off[dir], flags);
-        if (m > 0) k_validate_adj<<<grid_for(m), 256, 0, s>>>(n, m, o_adj[dir], flags);
+        HIP_TRY(o_off[dir].alloc(((size_t)n + 1) * sizeof(int64_t)));
+        HIP_TRY(o_adj[dir].alloc(((size_t)m + 1) * sizeof(int32_t)));
+        HIP_TRY(hipMemcpyAsync(o_off[dir].p, ho, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        if (m > 0) HIP_TRY(hipMemcpyAsync(o_adj[dir].p, ha, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        k_validate_off<<<grid_for((int64_t)n + 1), 256, 0, s>>>(n, m, o_off[dir].as<int64_t>(), flags);
+        if (m > 0) k_validate_adj<<<grid_for(m), 256, 0, s>>>(n, m, o_adj[dir].as<int32_t>(), flags);
     }
     uint32_t hflags = 0;
     HIP_TRY(hipMemcpyAsync(&hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (hflags & 2u) {
-        for (int dir = 0; dir < 2; ++dir) {
-            dev_free(o_off[dir]);
-            dev_free(o_adj[dir]);
-        }
-        dev_free(flags);
+    if (hflags & 2u)
         return fail(GPM_EINVAL, "CSR arrays are inconsistent (offsets not monotone or ids out of range)");
-    }
 
     // renumber by ascending total degree, ties by id (stable radix sort)
-    uint32_t *deg = nullptr, *deg2 = nullptr;
-    int32_t *ids = nullptr, *rank = nullptr;
-    HIP_TRY(hipMalloc(&deg, ((size_t)n + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&deg2, ((size_t)n + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&ids, ((size_t)n + 1) * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&rank, ((size_t)n + 1) * sizeof(int32_t)));
+    Scratch deg, deg2, ids, rank;
+    HIP_TRY(deg.alloc(((size_t)n + 1) * sizeof(uint32_t)));
+    HIP_TRY(deg2.alloc(((size_t)n + 1) * sizeof(uint32_t)));
+    HIP_TRY(ids.alloc(((size_t)n + 1) * sizeof(int32_t)));
+    HIP_TRY(rank.alloc(((size_t)n + 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&d.perm, ((size_t)n + 1) * sizeof(int32_t)));
     if (n > 0) {
-        k_total_degree<<<grid_for(n), 256, 0, s>>>(n, o_off[0], o_off[1], deg, ids);
+        k_total_degree<<<grid_for(n), 256, 0, s>>>(n, o_off[0].as<int64_t>(), o_off[1].as<int64_t>(), deg.as<uint32_t>(),
+                                                   ids.as<int32_t>());
         size_t tmp_bytes = 0;
-        void *tmp = nullptr;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, deg, deg2, ids, d.perm, (size_t)n, 0u, 32u, s));
-        HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, deg, deg2, ids, d.perm, (size_t)n, 0u, 32u, s));
-        int64_t *scratch_deg = nullptr;
-        HIP_TRY(hipMalloc(&scratch_deg, ((size_t)n + 1) * sizeof(int64_t)));
-        k_scatter_rank<<<grid_for(n), 256, 0, s>>>(n, d.perm, rank, o_off[0], scratch_deg);
+        Scratch tmp, scratch_deg;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, deg.as<uint32_t>(), deg2.as<uint32_t>(), ids.as<int32_t>(),
+                                          d.perm, (size_t)n, 0u, 32u, s));
+        HIP_TRY(tmp.alloc(tmp_bytes));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, deg.as<uint32_t>(), deg2.as<uint32_t>(), ids.as<int32_t>(),
+                                          d.perm, (size_t)n, 0u, 32u, s));
+        HIP_TRY(scratch_deg.alloc(((size_t)n + 1) * sizeof(int64_t)));
+        k_scatter_rank<<<grid_for(n), 256, 0, s>>>(n, d.perm, rank.as<int32_t>(), o_off[0].as<int64_t>(),
+                                                   scratch_deg.as<int64_t>());
         HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipFree(tmp));
-        HIP_TRY(hipFree(scratch_deg));
     }
-    int rc = rebuild_direction(d, 0, o_off[0], o_adj[0], m_out, rank, flags);
-    if (rc == GPM_OK && in_off) rc = rebuild_direction(d, 1, o_off[1], o_adj[1], m_in, rank, flags);
+    int rc = rebuild_direction(d, 0, o_off[0].as<int64_t>(), o_adj[0].as<int32_t>(), m_out, rank.as<int32_t>(), flags);
+    if (rc == GPM_OK && in_off)
+        rc = rebuild_direction(d, 1, o_off[1].as<int64_t>(), o_adj[1].as<int32_t>(), m_in, rank.as<int32_t>(), flags);
     if (rc != GPM_OK) return rc;
     if (!in_off) {
         d.off[1] = d.off[0];
@@ -643,26 +693,25 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
         d.m[1] = d.m[0];
     }
     if (labels) {
-        uint8_t *raw = nullptr;
-        HIP_TRY(hipMalloc(&raw, (size_t)n + 1));
+        Scratch raw;
+        HIP_TRY(raw.alloc((size_t)n + 1));
         HIP_TRY(hipMalloc(&d.label, (size_t)n + 1));
-        HIP_TRY(hipMemcpyAsync(raw, labels, (size_t)n, hipMemcpyHostToDevice, s));
-        if (n > 0) k_permute_labels<<<grid_for(n), 256, 0, s>>>(n, d.perm, raw, d.label);
+        HIP_TRY(hipMemcpyAsync(raw.p, labels, (size_t)n, hipMemcpyHostToDevice, s));
+        if (n > 0) k_permute_labels<<<grid_for(n), 256, 0, s>>>(n, d.perm, raw.as<uint8_t>(), d.label);
         HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipFree(raw));
     }
     HIP_TRY(hipMemcpyAsync(&hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *flags_out = hflags;
-    for (int dir = 0; dir < 2; ++dir) {
-        HIP_TRY(hipFree(o_off[dir]));
-        HIP_TRY(hipFree(o_adj[dir]));
+    for (int dir = 0; dir < 2; ++dir) {  // the caller's copies are no longer needed: make room for what follows
+        o_off[dir].release();
+        o_adj[dir].release();
     }
-    HIP_TRY(hipFree(deg));
-    HIP_TRY(hipFree(deg2));
-    HIP_TRY(hipFree(ids));
-    HIP_TRY(hipFree(rank));
-    HIP_TRY(hipFree(flags));
+    deg.release();
+    deg2.release();
+    ids.release();
+    rank.release();
+    flags_buf.release();
     d.gv.n = n;
     for (int dir = 0; dir < 2; ++dir) {
         d.gv.off[dir] = d.off[dir];
@@ -679,14 +728,24 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
     d.gv.hub = nullptr;
     if (hub_rows > 0 && n > 0) {
         const size_t bytes = (size_t)hub_rows * (size_t)(hub_rows / 32) * sizeof(uint32_t);
-        HIP_TRY(hipMalloc(&d.hub, bytes));
-        HIP_TRY(hipMemsetAsync(d.hub, 0, bytes, s));
-        d.gv.hub_base = (int32_t)std::max<int64_t>(0, (int64_t)n - hub_rows);
-        d.gv.hub_wpr = (int32_t)(hub_rows / 32);
-        d.gv.hub = d.hub;
-        k_hub_fill<<<(unsigned)(n - d.gv.hub_base), 256, 0, s>>>(d.gv, d.hub);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(s));
+        // Every kernel runs without the matrix (membership by binary search, rows from hashed list walks), so a
+        // device too full for it is not an error: halve the rows until it fits, or go without.
+        size_t want = bytes;
+        while (hub_rows >= 1024 && hipMalloc(&d.hub, want) != hipSuccess) {
+            (void)hipGetLastError();
+            d.hub = nullptr;
+            hub_rows = hub_rows / 2 / 64 * 64;
+            want = (size_t)hub_rows * (size_t)(hub_rows / 32) * sizeof(uint32_t);
+        }
+        if (d.hub) {
+            HIP_TRY(hipMemsetAsync(d.hub, 0, want, s));
+            d.gv.hub_base = (int32_t)std::max<int64_t>(0, (int64_t)n - hub_rows);
+            d.gv.hub_wpr = (int32_t)(hub_rows / 32);
+            d.gv.hub = d.hub;
+            k_hub_fill<<<(unsigned)(n - d.gv.hub_base), 256, 0, s>>>(d.gv, d.hub);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));
+        }
     }
 
     // per-vertex label histograms of the neighbours (symmetric labelled graphs)
@@ -712,27 +771,23 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
     const int64_t m_arcs = d.m[0];
     if (d.gv.labcnt && m_arcs > 0 && env_i64("GPM_NO_LABEL_SEGMENTS", 0) == 0 &&
         (size_t)n * (size_t)(d.gv.nlab + 1) * sizeof(uint32_t) <= ((size_t)4 << 30)) {
-        uint64_t *keys = nullptr, *keys2 = nullptr;
-        int32_t *vals = nullptr;
-        void *tmp = nullptr;
+        Scratch keys, keys2, vals, tmp;
         size_t tmp_bytes = 0;
         HIP_TRY(hipMalloc(&d.labseg, (size_t)n * (size_t)(d.gv.nlab + 1) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&d.adjL, ((size_t)m_arcs + 1) * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&keys, (size_t)m_arcs * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc(&keys2, (size_t)m_arcs * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc(&vals, (size_t)m_arcs * sizeof(int32_t)));
+        HIP_TRY(keys.alloc((size_t)m_arcs * sizeof(uint64_t)));
+        HIP_TRY(keys2.alloc((size_t)m_arcs * sizeof(uint64_t)));
+        HIP_TRY(vals.alloc((size_t)m_arcs * sizeof(int32_t)));
         k_label_segments<<<grid_for(n), 256, 0, s>>>(d.gv, d.labcnt, d.labseg);
-        k_segment_keys<<<grid_for(m_arcs), 256, 0, s>>>(d.gv, m_arcs, keys, vals);
+        k_segment_keys<<<grid_for(m_arcs), 256, 0, s>>>(d.gv, m_arcs, keys.as<uint64_t>(), vals.as<int32_t>());
         HIP_TRY(hipGetLastError());
         const unsigned end_bit = 8u + (unsigned)bits_for(n);
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, d.adjL, (size_t)m_arcs, 0u, end_bit, s));
-        HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, d.adjL, (size_t)m_arcs, 0u, end_bit, s));
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<int32_t>(),
+                                          d.adjL, (size_t)m_arcs, 0u, end_bit, s));
+        HIP_TRY(tmp.alloc(tmp_bytes));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<int32_t>(),
+                                          d.adjL, (size_t)m_arcs, 0u, end_bit, s));
         HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipFree(tmp));
-        HIP_TRY(hipFree(keys));
-        HIP_TRY(hipFree(keys2));
-        HIP_TRY(hipFree(vals));
         d.gv.adjL = d.adjL;
         d.gv.labseg = d.labseg;
     }
@@ -1164,6 +1219,7 @@ struct SearchArgs {
     gpm_row_sink sink;
     void *user;
     gpm_text_sink text_sink;  // non-null: matches leave as text lines formatted on the GPU
+    bool gather = false;        // several workers, output mode: rows are gathered on GPU 0 in rounds
     bool fixed_memory = false;  // gpm_hip_count_noalloc: level-by-level and fused-tail kernels only (the clique and
                                 // 4-cycle paths need large allocated buffers), roots cut into equal chunks
 };
@@ -1192,6 +1248,7 @@ static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
             HIP_TRY(hipMemsetAsync(d.pref[k], 0, sizeof(int64_t), d.stream));
         }
     }
+    if (ctx->t3.enabled && !d.over_rows) HIP_TRY(hipMalloc(&d.over_rows, 2 * (size_t)d.cap_rows * sizeof(int64_t)));
     if (!d.scan_tmp) {
         size_t bytes = 0;
         HIP_TRY(rocprim::inclusive_scan(nullptr, bytes, d.cnt[0], d.pref[0] + 1, (size_t)d.cap_rows,
@@ -1219,6 +1276,20 @@ static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
         HIP_TRY(hipMalloc(&d.aut_dev, bytes));
         if (!ctx->aut.empty())
             HIP_TRY(hipMemcpyAsync(d.aut_dev, ctx->aut.data(), ctx->aut.size(), hipMemcpyHostToDevice, d.stream));
+    }
+    const bool gather = !count_only && (ctx->devs.size() > 1 || !ctx->comms.empty()) && ctx->gather_on_device;
+    if (gather && (want_emit > d.cap_emit || !d.ag_send)) {
+        dev_free(d.ag_send);
+        dev_free(d.ag_recv);
+        dev_free(d.ag_counts);
+        d.ag_send = d.ag_recv = nullptr;
+        d.ag_counts = nullptr;
+        const size_t row_bytes = (size_t)GPM_MAXP * sizeof(int32_t);  // room for any pattern set later
+        HIP_TRY(hipMalloc(&d.ag_send, (size_t)want_emit * row_bytes));
+        // with communicators every GPU receives everybody's rows (all-gather); without, only GPU 0 collects
+        if (d.index == 0 || !ctx->comms.empty())
+            HIP_TRY(hipMalloc(&d.ag_recv, ctx->devs.size() * (size_t)want_emit * row_bytes));
+        HIP_TRY(hipMalloc(&d.ag_counts, (1 + ctx->devs.size()) * sizeof(unsigned long long)));
     }
     if (want_emit > d.cap_emit) {
         dev_free(d.emit);
@@ -1264,11 +1335,11 @@ static int timed_end(DevState &d, hipStream_t stream = nullptr) {
 }
 
 // Turn timing events into milliseconds; the stream must be idle.
-static int collect_times(DevState &d) {
+static int collect_times(DevState &d, bool trace) {
     for (size_t i = 0; i < d.events_used; ++i) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d.events[i].a, d.events[i].b));
-        if (getenv("GPM_TRACE"))
+        if (trace)
             fprintf(stderr, "gpm trace: %s class %d rows %lld ms %.3f\n", kKindNames[d.events[i].kind],
                     d.events[i].tag, (long long)d.events[i].rows, ms);
         d.ms_kind[d.events[i].kind] += ms;
@@ -1404,6 +1475,186 @@ static int deliver(const SearchArgs &a, DevState &d, const int32_t *rows, uint64
     return GPM_OK;
 }
 
+// ---- match lists of several GPUs, gathered on GPU 0 -------------------------
+//
+// The reference sends every match to rank 0 as one message and rank 0 writes it
+// (reference: src/gpm-par.c:181, :608-621).  Here every GPU of a context keeps
+// its finished rows in a send buffer; from time to time all workers meet in a
+// gather round: the row counts are exchanged, the lists padded to the longest
+// one are all-gathered over RCCL (every GPU ends up with everybody's rows), and
+// the worker of GPU 0 hands its copy to the writer -- as rows through a pinned
+// buffer, or formatted into text lines on GPU 0.  A context without
+// communicators (GPM_NO_RCCL=1) collects the lists with peer copies into GPU 0
+// instead.  A round forms when a worker's send buffer cannot take its next
+// batch (it asks for one and every other worker joins at its next check point)
+// and once more when every worker has run out of chunks.
+
+// Meet the other workers; returns through `rows` what each brings and whether
+// this is the round after which everybody is done.
+static int gather_meet(gpm_ctx *ctx, DevState &d, uint64_t rows[8], bool *last) {
+    auto &gs = ctx->gs;
+    const int n = (int)ctx->devs.size();
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    const uint64_t gen = gs.generation;
+    const int par = (int)(gen & 1);
+    gs.rows[par][d.index] = d.ag_rows;
+    if (++gs.arrived == n) {
+        gs.last[par] = gs.finished == n;
+        gs.arrived = 0;
+        gs.requested = false;
+        gs.generation++;
+        gs.rounds++;
+        ctx->cv.notify_all();
+    } else {
+        ctx->cv.wait(lk, [&] { return gs.generation != gen || ctx->stop; });
+        if (gs.generation == gen) return fail(GPM_ESINK, "the search was stopped");
+    }
+    for (int i = 0; i < n; ++i) rows[i] = gs.rows[par][i];
+    *last = gs.last[par];
+    return GPM_OK;
+}
+
+static int deliver(const SearchArgs &a, DevState &d, const int32_t *rows, uint64_t nrows);
+static int deliver_text(const SearchArgs &a, DevState &d, const int32_t *rows_dev, uint64_t nrows);
+
+// One gather round, run by every worker.  *last tells the caller that no further round follows.
+static int gather_round(const SearchArgs &a, DevState &d, bool *last) {
+    gpm_ctx *ctx = a.ctx;
+    const int n = (int)ctx->devs.size();
+    const int P = ctx->pv.P;
+    hipStream_t s = d.stream;
+    HIP_TRY(hipStreamSynchronize(s));  // this worker's rows are in its send buffer
+    uint64_t rows[8];
+    int rc = gather_meet(ctx, d, rows, last);
+    if (rc) return rc;
+    uint64_t longest = 0, all = 0;
+    for (int i = 0; i < n; ++i) {
+        longest = std::max(longest, rows[i]);
+        all += rows[i];
+    }
+    DevState &d0 = ctx->devs[0];
+    if (all) {
+        if (!ctx->comms.empty()) {
+            const Rccl &R = rccl();
+            // row counts first (every GPU learns how much of each padded list is real), then the lists
+            d.ctr_host[CTR_CLQ_CLASS0] = d.ag_rows;
+            HIP_TRY(hipMemcpyAsync(d.ag_counts, d.ctr_host + CTR_CLQ_CLASS0, sizeof(unsigned long long),
+                                   hipMemcpyHostToDevice, s));
+            int nrc = R.AllGather(d.ag_counts, d.ag_counts + 1, 1, RCCL_UINT64, ctx->comms[(size_t)d.index], s);
+            if (nrc == 0)
+                nrc = R.AllGather(d.ag_send, d.ag_recv, (size_t)longest * (size_t)P, RCCL_INT32,
+                                  ctx->comms[(size_t)d.index], s);
+            if (nrc != 0) return fail(GPM_ERUNTIME, "RCCL all-gather of the match lists failed: %s", R.GetErrorString(nrc));
+            if (d.index == 0) {
+                unsigned long long got[8] = {};
+                HIP_TRY(hipMemcpyAsync(got, d.ag_counts + 1, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                for (int i = 0; i < n; ++i)
+                    if (got[i] != rows[i])
+                        return fail(GPM_ERUNTIME, "gathered row count of GPU %d is %llu, its worker brought %llu", i, got[i],
+                                    (unsigned long long)rows[i]);
+            } else {
+                HIP_TRY(hipStreamSynchronize(s));
+            }
+        } else if (d.index == 0) {
+            for (int i = 0; i < n; ++i) {
+                if (!rows[i]) continue;
+                DevState &src = ctx->devs[(size_t)i];
+                HIP_TRY(hipMemcpyPeerAsync(d0.ag_recv + (size_t)i * (size_t)longest * (size_t)P, d0.dev, src.ag_send, src.dev,
+                                           (size_t)rows[i] * (size_t)P * sizeof(int32_t), s));
+            }
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+    }
+    d.ag_rows = 0;
+    if (ctx->comms.empty()) {  // peer copies read the others' send buffers: nobody refills before GPU 0 is done
+        uint64_t dummy[8];
+        bool dummy_last;
+        uint64_t keep = d.ag_rows;
+        rc = gather_meet(ctx, d, dummy, &dummy_last);
+        d.ag_rows = keep;
+        if (rc) return rc;
+    }
+    if (d.index == 0 && all) {
+        ctx->gs.gathered_rows += all;
+        for (int i = 0; i < n && !ctx->stop; ++i) {
+            const int32_t *part = d0.ag_recv + (size_t)i * (size_t)longest * (size_t)P;
+            if (!rows[i]) continue;
+            if (a.text_sink) {
+                if ((rc = deliver_text(a, d0, part, rows[i]))) return rc;
+                continue;
+            }
+            for (uint64_t r0 = 0; r0 < rows[i]; r0 += (uint64_t)d0.cap_emit) {
+                const uint64_t nr = std::min<uint64_t>((uint64_t)d0.cap_emit, rows[i] - r0);
+                HIP_TRY(hipMemcpyAsync(d0.emit_host, part + r0 * (uint64_t)P, (size_t)nr * (size_t)P * sizeof(int32_t),
+                                       hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if ((rc = deliver(a, d0, d0.emit_host, nr))) return rc;
+            }
+        }
+    }
+    return GPM_OK;
+}
+
+// Check point of a worker in gather mode: join the round somebody asked for.
+static int gather_check(const SearchArgs &a, DevState &d) {
+    if (!a.gather || !a.ctx->gs.requested.load()) return GPM_OK;
+    bool last;
+    return gather_round(a, d, &last);
+}
+
+// `n_emit` finished rows lie in d.emit on the device: pass them on -- to the send buffer of the gather
+// rounds, to the text formatter, or through the pinned buffer to the row sink.
+static int hand_over(const SearchArgs &a, DevState &d, uint64_t n_emit) {
+    gpm_ctx *ctx = a.ctx;
+    const int P = ctx->pv.P;
+    hipStream_t s = d.stream;
+    if (!n_emit) return GPM_OK;
+    if (a.gather) {
+        while (d.ag_rows + n_emit > (uint64_t)d.cap_emit) {  // no room: a round empties every send buffer
+            {
+                std::lock_guard<std::mutex> lk(ctx->mu);  // workers that have run out of chunks sleep on the flag
+                ctx->gs.requested = true;
+                ctx->cv.notify_all();
+            }
+            bool last;
+            int rc = gather_round(a, d, &last);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(d.ag_send + d.ag_rows * (uint64_t)P, d.emit, (size_t)n_emit * (size_t)P * sizeof(int32_t),
+                               hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));  // d.emit is free for the next batch
+        d.ag_rows += n_emit;
+        return gather_check(a, d);
+    }
+    if (a.text_sink) return deliver_text(a, d, d.emit, n_emit);
+    HIP_TRY(hipMemcpyAsync(d.emit_host, d.emit, (size_t)n_emit * (size_t)P * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return deliver(a, d, d.emit_host, n_emit);
+}
+
+// A worker that has run out of chunks keeps joining rounds until the one in which everybody is done.
+static int gather_finish(const SearchArgs &a, DevState &d) {
+    gpm_ctx *ctx = a.ctx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->gs.finished++;
+        if (ctx->gs.finished == (int)ctx->devs.size()) ctx->gs.requested = true;  // the closing round
+        ctx->cv.notify_all();
+    }
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(ctx->mu);
+            ctx->cv.wait(lk, [&] { return ctx->gs.requested.load() || ctx->stop; });
+            if (ctx->stop && !ctx->gs.requested.load()) return fail(GPM_ESINK, "the search was stopped");
+        }
+        bool last = false;
+        int rc = gather_round(a, d, &last);
+        if (rc) return rc;
+        if (last) return GPM_OK;
+    }
+}
+
 // Expand the partial matches F[k-1][0..nrows) (k ids each) to completion.
 static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
     gpm_ctx *ctx = a.ctx;
@@ -1424,12 +1675,12 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
         return timed_end(d);
     }
     if (a.count_only && ctx->use_tail && k == P - 3 && ctx->t3.enabled && !d.no_fuse3) {
-        if (!d.over_rows) HIP_TRY(hipMalloc(&d.over_rows, 2 * (size_t)d.cap_rows * sizeof(int64_t)));  // never for a fixed view
+        if (!d.over_rows) return fail(GPM_ESTATE, "hand-back lists of the three-level kernel were not allocated");
         int64_t *over1 = d.over_rows, *over2 = d.over_rows + d.cap_rows;
         HIP_TRY(hipMemsetAsync(d.ctr + CTR_OVER, 0, 2 * sizeof(unsigned long long), s));
         // 8 lanes and sets of up to 64 per partial match; what does not fit goes to 16 lanes with sets of up
         // to 256, then to whole waves with sets of up to 1024; what still does not fit goes level by level
-        const int64_t grp = env_i64("GPM_FUSE3_GROUP", 8);
+        const int64_t grp = ctx->fuse3_group;
         unsigned blocks = (unsigned)std::min<int64_t>((nrows * grp + 255) / 256, 1 << 16);
         int rc = timed_begin(d, GPM_KIND_TAIL, nrows);
         if (rc) return rc;
@@ -1450,10 +1701,10 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
         uint64_t n_over = 0;
         if ((rc = read_ctr(d, CTR_OVER, &n_over))) return rc;
         if (n_over == 0) return GPM_OK;
-        if (env_i64("GPM_FUSE3_WAVE", 1) == 0) {  // tests: straight to the level-by-level path
+        if (!ctx->fuse3_wave) {  // tests: straight to the level-by-level path
             over2 = over1;
         } else {
-            if (env_i64("GPM_FUSE3_MID", 1)) {  // sets of up to 256 with 16 lanes
+            if (ctx->fuse3_mid) {  // sets of up to 256 with 16 lanes
                 blocks = (unsigned)std::min<uint64_t>((n_over * 16 + 255) / 256, 1 << 16);
                 if ((rc = timed_begin(d, GPM_KIND_TAIL, (int64_t)n_over))) return rc;
                 k_tail3<16, 256><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, over1, (int64_t)n_over,
@@ -1496,8 +1747,8 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
         HIP_TRY(hipGetLastError());
         return timed_end(d);
     }
-    if (a.count_only && ctx->use_tail && k == P - 2 && ctx->ti.twin && env_i64("GPM_TWIN_GROUP", 1) > 0) {
-        const int64_t G = env_i64("GPM_TWIN_GROUP", 1);
+    if (a.count_only && ctx->use_tail && k == P - 2 && ctx->ti.twin && ctx->twin_group > 0) {
+        const int64_t G = ctx->twin_group;
         const unsigned blocks = (unsigned)std::min<int64_t>((nrows * G + 255) / 256, 1 << 16);
         int rc = timed_begin(d, GPM_KIND_TAIL, nrows);
         if (rc) return rc;
@@ -1572,18 +1823,8 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
                 uint64_t n_emit = 0;
                 rc = read_ctr(d, CTR_EMIT, &n_emit);
                 if (rc) return rc;
-                if (n_emit && a.text_sink) {
-                    d.canonical += n_emit;
-                    rc = deliver_text(a, d, d.emit, n_emit);
-                    if (rc) return rc;
-                } else if (n_emit) {
-                    HIP_TRY(hipMemcpyAsync(d.emit_host, d.emit, (size_t)n_emit * (size_t)P * sizeof(int32_t),
-                                           hipMemcpyDeviceToHost, s));
-                    HIP_TRY(hipStreamSynchronize(s));
-                    d.canonical += n_emit;
-                    rc = deliver(a, d, d.emit_host, n_emit);
-                    if (rc) return rc;
-                }
+                d.canonical += n_emit;
+                if ((rc = hand_over(a, d, n_emit))) return rc;
             } else {
                 HIP_TRY(hipMemsetAsync(d.ctr + CTR_LEVEL0 + k, 0, sizeof(unsigned long long), s));
                 k_extend<MODE_EXTEND><<<grid_for(gcount), 256, 0, s>>>(d.gv, ctx->pv, k, rows, d.pref[k - 1],
@@ -1743,18 +1984,15 @@ static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CLASSE
 static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows);
 
 // Largest universe the bitmap kernels take for a K-clique (larger roots go through the generic path).
-static int clique_max_d(int K) {
-    const int64_t cap = K <= 4 ? CLQ_BIG_MAX_D : CLQ_MAX_D;
-    return (int)std::min<int64_t>(cap, std::max<int64_t>(0, env_i64("GPM_CLIQUE_MAX_D", cap)));
+static int clique_max_d(const gpm_ctx *ctx) {
+    const int64_t cap = ctx->clique_k <= 4 ? CLQ_BIG_MAX_D : CLQ_MAX_D;
+    return (int)(ctx->clique_max_d_env < 0 ? cap : std::min<int64_t>(cap, ctx->clique_max_d_env));
 }
 
 // Largest universe of the in-LDS kernel's classes 0 and 1.  GPM_CLIQUE_SMALL_MAX lowers it for triangles and
 // 4-cliques (which have the build / count pair for everything larger), so that tests on small graphs run
 // those kernels.
-static int clique_small_max(int K) {
-    if (K > 4) return 256;
-    return (int)std::min<int64_t>(256, std::max<int64_t>(4, env_i64("GPM_CLIQUE_SMALL_MAX", 256)));
-}
+static int clique_small_max(const gpm_ctx *ctx) { return ctx->clique_k > 4 ? 256 : ctx->clique_small_max; }
 
 // One chunk of roots through the bitmap kernel, enqueued on the slot's stream
 // without any host round trip: the per-class root counts come from the chunk
@@ -1764,7 +2002,7 @@ static int clique_chunk(const SearchArgs &a, DevState &d, ChunkSlot &sl, const C
     gpm_ctx *ctx = a.ctx;
     hipStream_t s = sl.stream;
     HIP_TRY(hipMemsetAsync(sl.counts, 0, 8 * sizeof(unsigned long long), s));
-    k_clique_bin<<<grid_for(ch.hi - ch.lo), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx->clique_k), clique_small_max(ctx->clique_k), ch.lo, ch.hi, sl.lists,
+    k_clique_bin<<<grid_for(ch.hi - ch.lo), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx), clique_small_max(ctx), ch.lo, ch.hi, sl.lists,
                                                          d.clq_stride, sl.counts);
     HIP_TRY(hipGetLastError());
     d.rows_in[0] += (uint64_t)ch.n[0] + ch.n[1] + ch.n[2] + ch.n[3] + ch.n[4] + ch.n[5];
@@ -1816,18 +2054,16 @@ static int ensure_cycle4(gpm_ctx *ctx, DevState &d) {
     HIP_TRY(hipMemsetAsync(d.cyc_dense, 0, dense_bytes, s));
     HIP_TRY(hipMemsetAsync(d.cyc_wp, 0, sizeof(int64_t), s));
     if (m > 0) {
-        int64_t *len = nullptr;
-        void *tmp = nullptr;
+        Scratch len_buf, tmp;
         size_t tmp_bytes = 0;
-        HIP_TRY(hipMalloc(&len, (size_t)m * sizeof(int64_t)));
+        HIP_TRY(len_buf.alloc((size_t)m * sizeof(int64_t)));
+        int64_t *len = len_buf.as<int64_t>();
         k_cycle4_arc_paths<<<grid_for(m), 256, 0, s>>>(d.gv, m, len);
         HIP_TRY(hipGetLastError());
         HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, len, d.cyc_wp + 1, (size_t)m, rocprim::plus<int64_t>(), s));
-        HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-        HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, len, d.cyc_wp + 1, (size_t)m, rocprim::plus<int64_t>(), s));
+        HIP_TRY(tmp.alloc(tmp_bytes));
+        HIP_TRY(rocprim::inclusive_scan(tmp.p, tmp_bytes, len, d.cyc_wp + 1, (size_t)m, rocprim::plus<int64_t>(), s));
         HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipFree(tmp));
-        HIP_TRY(hipFree(len));
     }
     HIP_TRY(hipFuncSetAttribute((const void *)k_cycle4_heavy, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)CYC_HEAVY_LDS_BYTES));
@@ -1855,9 +2091,10 @@ static int prepare_chunks(gpm_ctx *ctx) {
     const bool oriented = P > 1 && ctx->pv.lv[1].src_part == PART_ABOVE;
     const int min_d = ctx->clique_k && ctx->use_clique ? ctx->clique_k - 1 : 0;
     const bool cyc = ctx->cycle4 && ctx->use_cycle4;
-    int64_t *cost = nullptr, *pref = nullptr;
-    HIP_TRY(hipMalloc(&cost, (size_t)nroots * sizeof(int64_t)));
-    HIP_TRY(hipMalloc(&pref, (size_t)nroots * sizeof(int64_t)));
+    Scratch cost_buf, pref_buf, tmp_buf;
+    HIP_TRY(cost_buf.alloc((size_t)nroots * sizeof(int64_t)));
+    HIP_TRY(pref_buf.alloc((size_t)nroots * sizeof(int64_t)));
+    int64_t *cost = cost_buf.as<int64_t>(), *pref = pref_buf.as<int64_t>();
     if (cyc) {
         int rc = ensure_cycle4(ctx, d);
         if (rc) return rc;
@@ -1866,16 +2103,15 @@ static int prepare_chunks(gpm_ctx *ctx) {
         k_root_cost<<<grid_for(nroots), 256, 0, s>>>(d.gv, oriented, min_d, lo, hi, cost);
     }
     size_t tmp_bytes = 0;
-    void *tmp = nullptr;
     HIP_TRY(rocprim::inclusive_scan(nullptr, tmp_bytes, cost, pref, (size_t)nroots, rocprim::plus<int64_t>(), s));
-    HIP_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-    HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, cost, pref, (size_t)nroots, rocprim::plus<int64_t>(), s));
+    HIP_TRY(tmp_buf.alloc(tmp_bytes));
+    HIP_TRY(rocprim::inclusive_scan(tmp_buf.p, tmp_bytes, cost, pref, (size_t)nroots, rocprim::plus<int64_t>(), s));
     std::vector<int64_t> hpref((size_t)nroots);
     HIP_TRY(hipMemcpyAsync(hpref.data(), pref, (size_t)nroots * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipFree(tmp));
-    HIP_TRY(hipFree(cost));
-    HIP_TRY(hipFree(pref));
+    tmp_buf.release();
+    cost_buf.release();
+    pref_buf.release();
     ctx->cyc_heavy_roots.clear();
     ctx->cyc_heavy_paths.clear();
     if (cyc)
@@ -1908,19 +2144,18 @@ static int prepare_chunks(gpm_ctx *ctx) {
         const int nch = (int)ctx->chunks.size();
         std::vector<int64_t> bounds((size_t)nch);
         for (int i = 0; i < nch; ++i) bounds[(size_t)i] = ctx->chunks[(size_t)i].lo;
-        int64_t *dbounds = nullptr;
-        unsigned int *table = nullptr;
-        HIP_TRY(hipMalloc(&dbounds, (size_t)nch * sizeof(int64_t)));
-        HIP_TRY(hipMalloc(&table, (size_t)nch * CLQ_CLASSES * sizeof(unsigned int)));
+        Scratch dbounds_buf, table_buf;
+        HIP_TRY(dbounds_buf.alloc((size_t)nch * sizeof(int64_t)));
+        HIP_TRY(table_buf.alloc((size_t)nch * CLQ_CLASSES * sizeof(unsigned int)));
+        int64_t *dbounds = dbounds_buf.as<int64_t>();
+        unsigned int *table = table_buf.as<unsigned int>();
         HIP_TRY(hipMemcpyAsync(dbounds, bounds.data(), (size_t)nch * sizeof(int64_t), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(table, 0, (size_t)nch * CLQ_CLASSES * sizeof(unsigned int), s));
-        k_chunk_classes<<<grid_for(nroots), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx->clique_k), clique_small_max(ctx->clique_k), lo, hi, dbounds, nch,
+        k_chunk_classes<<<grid_for(nroots), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx), clique_small_max(ctx), lo, hi, dbounds, nch,
                                                          table);
         std::vector<unsigned int> htable((size_t)nch * CLQ_CLASSES);
         HIP_TRY(hipMemcpyAsync(htable.data(), table, htable.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipFree(dbounds));
-        HIP_TRY(hipFree(table));
         for (int i = 0; i < nch; ++i)
             for (int c = 0; c < CLQ_CLASSES; ++c)
                 ctx->chunks[(size_t)i].n[c] = htable[(size_t)i * CLQ_CLASSES + (size_t)c];
@@ -1975,7 +2210,9 @@ static int device_search(const SearchArgs &a, DevState &d) {
     const auto t_begin = std::chrono::steady_clock::now();
     uint64_t next_fixed = 0;  // fixed-memory search: equal chunks of the root range, no chunk table
     Chunk fixed_chunk{};
+    d.ag_rows = 0;
     while (!ctx->stop) {
+        if ((rc = gather_check(a, d))) return rc;
         uint64_t c;
         if (a.fixed_memory) {
             c = next_fixed++;
@@ -2010,8 +2247,7 @@ static int device_search(const SearchArgs &a, DevState &d) {
             const auto &hv = ctx->cyc_heavy_roots;
             // heavy roots of the chunk, CYC_BATCH per launch; the light launches keep a stream (and with it
             // a hardware queue) of their own, so the batches alternate between the other three
-            const int64_t hblock = std::max<int64_t>(256, env_i64("GPM_CYC_HEAVY_BLOCK", 2048)) / 256 * 256;
-            const int64_t span = std::max<int64_t>(1, env_i64("GPM_CYC_SPAN", (int64_t)1 << 18) / hblock) * hblock;
+            const int64_t hblock = ctx->cyc_heavy_block, span = ctx->cyc_span;
             size_t h = (size_t)(std::lower_bound(hv.begin(), hv.end(), lo) - hv.begin());
             while (h < hv.size() && hv[h] < hi) {
                 CycBatch b{};
@@ -2036,7 +2272,7 @@ static int device_search(const SearchArgs &a, DevState &d) {
                 if (d.events_used > 4096) {
                     for (auto &x : d.slots) HIP_TRY(hipStreamSynchronize(x.stream));
                     HIP_TRY(hipStreamSynchronize(s));
-                    if ((rc = collect_times(d))) return rc;
+                    if ((rc = collect_times(d, ctx->trace))) return rc;
                 }
             }
             continue;
@@ -2053,7 +2289,7 @@ static int device_search(const SearchArgs &a, DevState &d) {
             sl.busy = true;
             if (d.events_used > 4096) {
                 for (auto &x : d.slots) HIP_TRY(hipStreamSynchronize(x.stream));
-                if ((rc = collect_times(d))) return rc;
+                if ((rc = collect_times(d, ctx->trace))) return rc;
             }
             continue;
         }
@@ -2070,16 +2306,8 @@ static int device_search(const SearchArgs &a, DevState &d) {
                 for (uint64_t r0 = 0; r0 < n0; r0 += (uint64_t)d.cap_emit) {
                     uint64_t cnt = std::min<uint64_t>((uint64_t)d.cap_emit, n0 - r0);
                     k_emit_roots<<<grid_for((int64_t)cnt), 256, 0, s>>>((int64_t)cnt, d.F[0] + r0, d.perm, d.emit);
-                    if (a.text_sink) {
-                        rc = deliver_text(a, d, d.emit, cnt);
-                        if (rc) return rc;
-                        continue;
-                    }
-                    HIP_TRY(hipMemcpyAsync(d.emit_host, d.emit, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                           s));
-                    HIP_TRY(hipStreamSynchronize(s));
-                    rc = deliver(a, d, d.emit_host, cnt);
-                    if (rc) return rc;
+                    HIP_TRY(hipGetLastError());
+                    if ((rc = hand_over(a, d, cnt))) return rc;
                 }
             }
             continue;
@@ -2088,11 +2316,12 @@ static int device_search(const SearchArgs &a, DevState &d) {
         if (rc) return rc;
         if (d.events_used > 4096) {
             HIP_TRY(hipStreamSynchronize(s));
-            rc = collect_times(d);
+            rc = collect_times(d, ctx->trace);
             if (rc) return rc;
         }
     }
-    if (getenv("GPM_TRACE"))
+    if (a.gather && !ctx->stop && (rc = gather_finish(a, d))) return rc;
+    if (ctx->trace)
         fprintf(stderr, "gpm trace: all chunks enqueued %.3f ms after the search began\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     if (cyc)
@@ -2108,7 +2337,7 @@ static int device_search(const SearchArgs &a, DevState &d) {
     }
     HIP_TRY(hipMemcpyAsync(d.ctr_host, d.ctr, CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    rc = collect_times(d);
+    rc = collect_times(d, ctx->trace);
     if (rc) return rc;
     if (a.count_only) d.canonical = d.ctr_host[CTR_MATCHES] + d.ctr_host[CTR_TAIL_MATCHES] + p1_rows;
     else if (P == 1) d.canonical = p1_rows;
@@ -2137,9 +2366,16 @@ static int search_impl(gpm_ctx *ctx, int count_only, gpm_row_sink sink, gpm_text
         int prc = prepare_chunks(ctx);
         if (prc) return prc;
     }
-    SearchArgs a{ctx, count_only != 0, ctx->devs.size() == 1, sink, user, text_sink};
+    // one worker thread per GPU; a single GPU searches on the calling thread, unless it has a communicator
+    // (GPM_FORCE_RCCL=1), in which case output mode runs the gather rounds of a multi-GPU context with one worker
+    const bool threaded = ctx->devs.size() > 1 || (!ctx->comms.empty() && !count_only);
+    SearchArgs a{ctx, count_only != 0, !threaded, sink, user, text_sink};
+    a.gather = !count_only && threaded && ctx->gather_on_device;
+    ctx->gs.arrived = ctx->gs.finished = 0;
+    ctx->gs.requested = false;
+    ctx->gs.rounds = ctx->gs.gathered_rows = 0;
     int rc = GPM_OK;
-    if (ctx->devs.size() == 1) {
+    if (!threaded) {
         rc = device_search(a, ctx->devs[0]);
     } else {
         std::vector<std::thread> threads;
@@ -2247,6 +2483,8 @@ static int search_impl(gpm_ctx *ctx, int count_only, gpm_row_sink sink, gpm_text
                                                (unsigned long long)reduced, (unsigned long long)st.canonical);
         st.canonical = reduced;
     }
+    st.gather_rounds = ctx->gs.rounds;
+    st.gathered_rows = ctx->gs.gathered_rows;
     st.matches = st.canonical * ctx->plan.n_aut;
     st.ms_total =
         1e3 * (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
@@ -2323,7 +2561,7 @@ extern "C" int gpm_hip_count_noalloc(gpm_ctx *ctx, uint64_t *total) {
     if (used + v.scan_tmp_bytes > NOALLOC_BYTES)
         return fail(GPM_ERUNTIME, "fixed scratch layout needs %zu bytes", used + v.scan_tmp_bytes);
     ctx->stop = false;
-    SearchArgs a{ctx, true, true, nullptr, nullptr, nullptr, true};
+    SearchArgs a{ctx, true, true, nullptr, nullptr, nullptr, false, true};
     int rc = device_search(a, v);
     if (rc != GPM_OK) {
         (void)hipStreamSynchronize(v.stream);

@@ -691,14 +691,26 @@ def test_counts_are_reduced_over_rccl(monkeypatch):
         assert m.findMatches(count_only=True) == want
         rows = m.findMatches(count_only=False)
         assert len(rows) == want
+        assert util.sorted_lines_md5(util.rows_to_text(rows)) == spec["sorted_md5"]
+        st = m.stats()  # output mode went through a gather round with ncclAllGather (one rank)
+        assert st.gather_rounds >= 1 and st.gathered_rows == st.canonical
+        assert util.sorted_lines_md5(m.findMatchesText()) == spec["sorted_md5"]
     m.close()
 
 
+@pytest.mark.parametrize("gather", ["device", "device_small_rounds", "host"])
 @pytest.mark.parametrize("workers", [2, 3])
-def test_several_workers_in_one_context(workers, monkeypatch):
+def test_several_workers_in_one_context(workers, gather, monkeypatch):
     """The multi-GPU driver of one context -- one host thread per worker, chunks from one cursor,
-    rows and text handed to the caller's thread -- with every worker on GPU 0."""
+    the workers' match lists collected on GPU 0 in gather rounds (peer copies here, as there are no
+    communicators between workers that share GPU 0; many small rounds with a tiny send buffer) or
+    handed to the host by every worker, rows and text delivered on the caller's thread."""
     monkeypatch.setenv("GPM_NO_RCCL", "1")
+    if gather == "host":
+        monkeypatch.setenv("GPM_GATHER", "host")
+    if gather == "device_small_rounds":
+        monkeypatch.setenv("GPM_CHUNK_ROOTS", "64")
+        monkeypatch.setenv("GPM_EMIT_ROWS", "3000")
     for name in ("rmat10_clique4", "rmat8_house", "rmat10_cycle4", "plaw9_tree5_labelled4"):
         spec = next(g for g in GOLDEN if g["name"] == name)
         n, s, d = util.build_graph(spec)
@@ -713,6 +725,13 @@ def test_several_workers_in_one_context(workers, monkeypatch):
         if spec["count"] <= ROWS_MAX:
             rows = m.findMatches(count_only=False)
             assert util.sorted_lines_md5(util.rows_to_text(rows)) == spec["sorted_md5"]
+            st = m.stats()
+            if gather == "host":
+                assert st.gather_rounds == 0
+            else:
+                assert st.gather_rounds >= 1 and st.gathered_rows == st.canonical
+                if gather == "device_small_rounds" and st.canonical > 20000:
+                    assert st.gather_rounds > 3
             text = m.findMatchesText()
             assert util.sorted_lines_md5(text) == spec["sorted_md5"]
         m.close()
