@@ -122,6 +122,11 @@ def host_lib():
         lib.makeGraphOrdering.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.buildPlan.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(gpm_plan), ctypes.c_char_p,
                                   ctypes.c_int]
+        lib.graphStatsNew.restype = ctypes.c_void_p
+        lib.graphStatsNew.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        lib.graphStatsFree.argtypes = [ctypes.c_void_p]
+        lib.buildPlanForGraph.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.POINTER(gpm_plan), ctypes.c_char_p, ctypes.c_int]
         lib.readInput.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                   ctypes.c_char_p, ctypes.c_int]
         lib.free.argtypes = [ctypes.c_void_p]
@@ -209,11 +214,37 @@ def makeGraphOrdering(pattern_ptr):
     return o, par, rc == 0
 
 
-def make_plan(pattern_ptr, flags: int) -> gpm_plan:
+class GraphStats:
+    """Degree distribution of a data graph for the planner's cost model (GraphStats of mpi_amd/host/plan.h)."""
+
+    def __init__(self, n, out_off, in_off=None):
+        oo = np.ascontiguousarray(out_off, dtype=np.int64)
+        io = None if in_off is None else np.ascontiguousarray(in_off, dtype=np.int64)
+        self.ptr = ctypes.c_void_p(host_lib().graphStatsNew(n, oo.ctypes.data, None if io is None else io.ctypes.data))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                host_lib().graphStatsFree(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def graph_stats(n, out_off, in_off=None) -> GraphStats:
+    return GraphStats(n, out_off, in_off)
+
+
+def make_plan(pattern_ptr, flags: int, stats: GraphStats | None = None) -> gpm_plan:
+    """Plan a pattern; with the data graph's degree statistics the binding order is chosen by cost."""
     lib = host_lib()
     plan = gpm_plan()
     err = ctypes.create_string_buffer(256)
-    if lib.buildPlan(pattern_ptr, flags, ctypes.byref(plan), err, 256) != 0:
+    if stats is None:
+        rc = lib.buildPlan(pattern_ptr, flags, ctypes.byref(plan), err, 256)
+    else:
+        rc = lib.buildPlanForGraph(pattern_ptr, flags, stats.ptr, ctypes.byref(plan), err, 256)
+    if rc != 0:
         raise GpmError(err.value.decode())
     return plan
 
@@ -255,6 +286,7 @@ class Matcher:
             lb = np.ascontiguousarray(labels, dtype=np.uint8)
         ptr = lambda a: a.ctypes.data if a is not None and a.size else (a.ctypes.data if a is not None else None)
         self._check(self.lib.gpm_hip_upload_graph(self.ctx, n, ptr(oo), ptr(oa), ptr(io), ptr(ia), ptr(lb)))
+        self._stats = graph_stats(n, oo, io)
         return self.info()
 
     def info(self) -> gpm_graph_info:
@@ -276,7 +308,7 @@ class Matcher:
             flags |= PLAN_REFERENCE_ORDER
         p = make_pattern(pattern, labels)
         try:
-            plan = make_plan(p, flags)
+            plan = make_plan(p, flags, getattr(self, "_stats", None))
         finally:
             host_lib().freePattern(p)
         self.set_plan(plan)

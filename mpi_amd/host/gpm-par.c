@@ -146,7 +146,10 @@ int main(int argc, char *argv[]) {
     if (graph->simple) flags |= PLAN_DEGREE_FILTER;
     if (graph->simple && envInt("GPM_SYMBREAK", 1)) flags |= PLAN_BREAK_SYMMETRY;
     gpm_plan plan;
-    if (buildPlan(pattern, flags, &plan, err, sizeof err) != 0) die("bad pattern", err);
+    /* the binding order is chosen by cost from the data graph's degree distribution (simple symmetric graphs) */
+    GraphStats *stats = sameLists ? graphStatsNew(graph->nodesCount, graph->outOffsets, NULL) : NULL;
+    if (buildPlanForGraph(pattern, flags, stats, &plan, err, sizeof err) != 0) die("bad pattern", err);
+    graphStatsFree(stats);
     if (gpm_hip_set_plan(ctx, &plan) != 0) die("plan rejected", gpm_hip_last_error());
     printf("Distribution time[s]: %d\n", (int)(wallSeconds() - startDistTime));
     fflush(stdout);

@@ -26,6 +26,42 @@ enum {
                               * default: same order with the leaves moved to the end */
 };
 
+/* Degree statistics of the data graph for the cost model of the binding order: the distinct values of the
+ * (undirected) degree, capped at sqrt(sum of degrees) so that the expected-count formula below stays
+ * meaningful on heavy-tailed graphs (an arc between two vertices exists with probability at most one),
+ * and how many vertices have each. */
+typedef struct {
+    int32_t nValues;
+    double *value; /* ascending */
+    double *count;
+    double moments[MAX_MATCH_SIZE];   /* moments[j] = sum over the vertices of degree^j */
+    double *cdf[MAX_MATCH_SIZE];      /* cdf[j][i] = sum over values[0..i] of count * value^j */
+} GraphStats;
+
+GraphStats *graphStatsNew(int32_t n, const int64_t *outOffsets, const int64_t *inOffsets);
+void graphStatsFree(GraphStats *s);
+
+/* As buildPlan, with the binding order chosen by cost when the data graph is simple and symmetric
+ * (PLAN_SYMMETRIC_DATA and PLAN_DEGREE_FILTER set), stats is given and neither PLAN_REFERENCE_ORDER nor
+ * GPM_PLAN_ORDER asks for another order.
+ *
+ * Cost of an order = expected number of partial matches the search handles one by one, summed over the
+ * levels.  For the partial pattern H on the first k vertices: the product over its vertices v of
+ * moments[deg_H(v)], divided by moments[1]^|E(H)| -- the expected copies of H in a random graph with the
+ * data graph's degrees -- times the probability that the symmetry-breaking bounds among those vertices
+ * hold.  The library orders vertices by degree, so a bound m(a) < m(b) says "a has the lower degree"; the
+ * probability is estimated by drawing every vertex's degree from the degree distribution weighted by
+ * degree^deg_H(v) (fixed seed).  This is what makes extending a partial match from the lower end of a bound
+ * much cheaper than from the upper end on a skewed graph.  Levels counted in closed form cost nothing:
+ * leaves bound last, and the last two levels when their vertices are not adjacent (independent or twin
+ * candidate sets, counted per partial match of the level before); otherwise the last level alone is
+ * fused into the one before it.  Candidates are all orders of the non-leaf vertices that keep every
+ * prefix connected (patterns of 4 to 8 such vertices) and, when the default order ends in two non-adjacent
+ * vertices, end in two non-adjacent vertices as well -- the model underestimates dense partial patterns on
+ * graphs with a dense core, so it is not allowed to add a level that is handled row by row; the default order (reference numbering with leaves
+ * and twins last) is kept unless the best candidate is expected to do less than half its work. */
+int buildPlanForGraph(const Pattern *p, int flags, const GraphStats *stats, gpm_plan *plan, char *err, int errLen);
+
 /* Fill *plan for pattern p.  On success plan->aut points to a malloc'd table
  * the caller frees with free() (NULL when PLAN_BREAK_SYMMETRY is off or the
  * pattern has no symmetry).  Returns 0 or -1 with a message in err. */

@@ -800,3 +800,48 @@ def test_bench_with_two_ranks_from_a_plain_shell(tmp_path):
     assert len(out["search_ms_per_step_by_rank"]) == 2 and len(out["chunks_per_step_by_rank"]) == 2
     assert sum(out["chunks_per_step_by_rank"]) >= 2  # every chunk of a step taken by one of the two ranks
     assert out["roofline"]["frac"] > 0 and out["scaling"] == "strong"
+
+
+@pytest.mark.parametrize("pname", ["house", "diamond", "cycle4", "k4_dag", "tree5_dir"])
+def test_every_binding_order_gives_the_oracle_result(pname, monkeypatch):
+    """Every connected binding order of a pattern (GPM_PLAN_ORDER), with and without symmetry breaking:
+    the count and, through the output path, the multiset of rows equal the oracle's."""
+    from tests.test_host import _connected_orders
+    pat = gen.PATTERNS[pname]
+    if pname in ("k4_dag", "tree5_dir"):
+        n = 40
+        s, d = util.rand_digraph(n, 1, 5, 3, False)
+    else:
+        n, s, d = util.build_graph({"graph": "rmat", "scale": 7, "ef": 6, "seed": 3})
+    want, want_rows, _ = util.oracle_matches(n, s, d, pat)
+    want_sorted = sorted(map(tuple, want_rows.tolist()))
+    m = binding.Matcher(1)
+    upload(m, n, s, d)
+    for perm in _connected_orders(pat):
+        monkeypatch.setenv("GPM_PLAN_ORDER", ",".join(map(str, perm)))
+        for symbreak in (True, False):
+            m.set_pattern(pat, symbreak=symbreak)
+            assert m.findMatches(count_only=True) == want, (perm, symbreak)
+        rows = m.findMatches(count_only=False)
+        assert sorted(map(tuple, rows.tolist())) == want_sorted, perm
+    m.close()
+
+
+def test_the_cost_model_s_order_for_the_house_pattern(monkeypatch):
+    """R-MAT scale 13: the order the planner picks from the degree distribution, the default order and the
+    reference order count the same embeddings; the picked order materialises fewer partial matches."""
+    off, adj = gen.rmat(13, 16, seed=1)
+    o, a = gen.csr_to_numpy(off, adj)
+    n = 1 << 13
+    got = {}
+    for mode in ("cost", "default", "reference"):
+        monkeypatch.setenv("GPM_PLAN_ORDER", mode)
+        m = binding.Matcher(1)
+        m.upload(n, o, a)
+        m.set_pattern(gen.PATTERNS["house"])
+        c = m.findMatches(count_only=True)
+        st = m.stats()
+        got[mode] = (c, int(st.rows_in[2]))
+        m.close()
+    assert got["cost"][0] == got["default"][0] == got["reference"][0] == 139982822016
+    assert got["cost"][1] * 3 < got["default"][1]

@@ -448,3 +448,69 @@ def test_host_code_and_oracle_under_sanitizers(tmp_path):
                            timeout=600)
         assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
         assert got.read_bytes() == open(out, "rb").read()
+
+
+def _connected_orders(pattern):
+    import itertools
+    P, arcs = pattern
+    nbr = {v: set() for v in range(1, P + 1)}
+    for a, b in arcs:
+        if a != b:
+            nbr[a].add(b)
+            nbr[b].add(a)
+    return [perm for perm in itertools.permutations(range(1, P + 1))
+            if all(any(w in nbr[perm[k]] for w in perm[:k]) for k in range(1, P))]
+
+
+def test_binding_order_chosen_by_cost():
+    """With the degree distribution of a skewed graph the planner moves the house pattern's third vertex to the
+    lower end of its ordering bound and keeps the closed-form tail; patterns whose default order is already
+    the cheapest of its class (octahedron, cliques, trees) keep it; the reference order and explicit orders
+    are still available."""
+    off, adj = gen.rmat(13, 16, seed=1)
+    o, _ = gen.csr_to_numpy(off, adj)
+    st = binding.graph_stats(1 << 13, o)
+    flags = binding.PLAN_SYMMETRIC_DATA | binding.PLAN_BREAK_SYMMETRY | binding.PLAN_DEGREE_FILTER
+
+    def order_of(name, stats, extra=0):
+        p = binding.make_pattern(gen.PATTERNS[name])
+        try:
+            plan = binding.make_plan(p, flags | extra, stats)
+        finally:
+            binding.host_lib().freePattern(p)
+        return [x + 1 for x in list(plan.order)[:plan.n_levels]], plan
+
+    house, plan = order_of("house", st)
+    assert house != order_of("house", None)[0]
+    assert house[:2] in ([1, 4], [4, 1], [2, 3], [3, 2], [1, 2], [2, 1]) and sorted(house[-2:]) in ([3, 5], [4, 5])
+    # the third vertex hangs off the vertex the bounds make the smaller one
+    lower = {plan.lower_level[k][j] for k in range(5) for j in range(plan.n_lower[k])}
+    assert plan.src_level[2] in lower or plan.n_lower[plan.src_level[2]] == 0
+    for name in ("k6_minus_pm", "clique4", "clique5", "tree5", "diamond", "k6_minus_e"):
+        assert order_of(name, st)[0] == order_of(name, None)[0], name
+    assert order_of("house", st, binding.PLAN_REFERENCE_ORDER)[0] == [1, 2, 3, 4, 5]
+
+
+def test_explicit_binding_orders_are_valid_plans(monkeypatch):
+    """GPM_PLAN_ORDER="3,1,2,...": every connected order gives a plan whose levels list exactly the pattern's
+    edges (tree arc + constraints); an order with a disconnected prefix is rejected."""
+    pat = gen.PATTERNS["house"]
+    P, arcs = pat
+    edges = {frozenset((a, b)) for a, b in arcs}
+    for perm in _connected_orders(pat):
+        monkeypatch.setenv("GPM_PLAN_ORDER", ",".join(map(str, perm)))
+        p = binding.make_pattern(pat)
+        plan = binding.make_plan(p, binding.PLAN_SYMMETRIC_DATA)
+        binding.host_lib().freePattern(p)
+        assert [x + 1 for x in list(plan.order)[:P]] == list(perm)
+        seen = set()
+        for k in range(1, P):
+            seen.add(frozenset((perm[k], perm[plan.src_level[k]])))
+            for j in range(plan.n_cons[k]):
+                seen.add(frozenset((perm[k], perm[plan.cons_level[k][j]])))
+        assert seen == edges, perm
+    monkeypatch.setenv("GPM_PLAN_ORDER", "1,3,2,4,5")  # 3 is not adjacent to 1
+    p = binding.make_pattern(pat)
+    with pytest.raises(binding.GpmError):
+        binding.make_plan(p, binding.PLAN_SYMMETRIC_DATA)
+    binding.host_lib().freePattern(p)
