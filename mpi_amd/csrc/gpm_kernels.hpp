@@ -1682,7 +1682,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
 // of the list, read row j's words over the column tile from LDS, 16 bytes per
 // lane, and add |row_i ^ row_j|.
 //
-// Listing.  Lane l holds 16 of the row's 1024 positions; an inclusive scan of
+// Listing.  Lane l holds 16 of the row's 1024 positions (four bits of four words spread over the row); an inclusive scan of
 // the per-lane bit counts over the wave gives every lane the place of its first
 // entry, and each lane then writes its own entries (the order inside a list
 // does not matter).  List entries are row offsets in 16-byte slots (j * L), so
@@ -1761,9 +1761,13 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
     const int my_first = two ? (blk & 1) + 2 * (blk >> 2) : blk;
     const int my_step = two ? 4 : GPM_WAVE >> lg;
     const uint16_t *Jmine = J + 512 * my_res;
-    // listing: this lane's 16 positions
-    const int word_of_lane = lane & 31, half_of_lane = lane >> 5;
-    const uint32_t pos0 = (uint32_t)(32 * word_of_lane + 16 * half_of_lane);
+    // listing: lane l looks at four bits of each of the words (l & 7) + 8 k, k = 0..3: bits 4 (l >> 3) .. + 3.
+    // A row is dense where its universe holds the highest-degree vertices (its last positions), and a lane
+    // that held 16 neighbouring positions of that region would write its entries long after the others were
+    // done; this way every lane gets a share of every quarter of the row.
+    const int word_of_lane = lane & 31;
+    const int wg = lane & 7, nib = lane >> 3;
+    const uint32_t pos0 = (uint32_t)(32 * wg + 4 * nib);
     const uint32_t *lane_base = tile + 4 * sub;
 
     uint64_t total = 0;
@@ -1778,7 +1782,10 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
     }
     while (i < i_hi) {
         // list the set bits of row i over tile a
-        uint32_t bits = (mine >> (16 * half_of_lane)) & 0xffffu;
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            bits |= (((uint32_t)__shfl((int)mine, wg + 8 * k, GPM_WAVE) >> (4 * nib)) & 0xfu) << (4 * k);
         const uint32_t c = two ? (uint32_t)__popc(bits & 0x5555u) | ((uint32_t)__popc(bits & 0xaaaau) << 16)
                                : (uint32_t)__popc(bits);
         const uint32_t incl = wave_incl_scan_u32(c);
@@ -1788,7 +1795,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
             const uint32_t b = (uint32_t)__builtin_ctz(bits);
             bits &= bits - 1;
             const bool odd = two && (b & 1u);
-            J[odd ? at1 : at0] = (uint16_t)((pos0 + b) << lg);
+            J[odd ? at1 : at0] = (uint16_t)((pos0 + ((b >> 2) << 8) + (b & 3u)) << lg);  // word (b >> 2) * 8 further on
             at1 += odd;
             at0 += !odd;
         }
