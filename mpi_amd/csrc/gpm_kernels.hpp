@@ -1760,7 +1760,11 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
     const int my_res = two ? (blk >> 1) & 1 : 0;
     const int my_first = two ? (blk & 1) + 2 * (blk >> 2) : blk;
     const int my_step = two ? 4 : GPM_WAVE >> lg;
-    const uint16_t *Jmine = J + 512 * my_res;
+    // The even list grows up from J[0], the odd list down from J[1023] (together they hold at most 1023
+    // entries): entry t of one and entry t of the other then never lie on the same LDS bank, which they
+    // would if the second list started half way (1024 bytes on).
+    const uint16_t *Jmine = my_res ? J + 1023 : J;
+    const int jdir = my_res ? -1 : 1;
     // listing: lane l looks at four bits of each of the words (l & 7) + 8 k, k = 0..3: bits 4 (l >> 3) .. + 3.
     // A row is dense where its universe holds the highest-degree vertices (its last positions), and a lane
     // that held 16 neighbouring positions of that region would write its entries long after the others were
@@ -1790,13 +1794,13 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
                                : (uint32_t)__popc(bits);
         const uint32_t incl = wave_incl_scan_u32(c);
         const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, GPM_WAVE - 1);
-        uint32_t at0 = (incl - c) & 0xffffu, at1 = 512u + ((incl - c) >> 16);  // next free entry, even / odd list
+        uint32_t at0 = (incl - c) & 0xffffu, at1 = 1023u - ((incl - c) >> 16);  // next free entry, even / odd list
         while (bits) {
             const uint32_t b = (uint32_t)__builtin_ctz(bits);
             bits &= bits - 1;
             const bool odd = two && (b & 1u);
             J[odd ? at1 : at0] = (uint16_t)((pos0 + ((b >> 2) << 8) + (b & 3u)) << lg);  // word (b >> 2) * 8 further on
-            at1 += odd;
+            at1 -= odd;
             at0 += !odd;
         }
         // the next row's words are requested once this row's have been used
@@ -1813,16 +1817,16 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
             uint32_t acc = 0;
             int t = my_first;
             for (; t + 3 * my_step < my_len; t += 4 * my_step) {  // four independent row reads in flight
-                const u32x4 r0 = load4(lane_base + ((uint32_t)Jmine[t] << 2));
-                const u32x4 r1 = load4(lane_base + ((uint32_t)Jmine[t + my_step] << 2));
-                const u32x4 r2 = load4(lane_base + ((uint32_t)Jmine[t + 2 * my_step] << 2));
-                const u32x4 r3 = load4(lane_base + ((uint32_t)Jmine[t + 3 * my_step] << 2));
+                const u32x4 r0 = load4(lane_base + ((uint32_t)Jmine[jdir * t] << 2));
+                const u32x4 r1 = load4(lane_base + ((uint32_t)Jmine[jdir * (t + my_step)] << 2));
+                const u32x4 r2 = load4(lane_base + ((uint32_t)Jmine[jdir * (t + 2 * my_step)] << 2));
+                const u32x4 r3 = load4(lane_base + ((uint32_t)Jmine[jdir * (t + 3 * my_step)] << 2));
                 acc = and_popc_add4(C, r0, acc);
                 acc = and_popc_add4(C, r1, acc);
                 acc = and_popc_add4(C, r2, acc);
                 acc = and_popc_add4(C, r3, acc);
             }
-            for (; t < my_len; t += my_step) acc = and_popc_add4(C, load4(lane_base + ((uint32_t)Jmine[t] << 2)), acc);
+            for (; t < my_len; t += my_step) acc = and_popc_add4(C, load4(lane_base + ((uint32_t)Jmine[jdir * t] << 2)), acc);
             total += acc;
         }
         wave_lds_sync();

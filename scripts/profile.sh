@@ -5,7 +5,7 @@
 # gpurun_out/prof_<tag>/ ; scripts/summarize_profile.py turns them into the
 # files kept under profiles/.
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
