@@ -306,7 +306,10 @@ def main():
 
     cursor = gdist.open_cursor(f"bench_{os.environ.get('MASTER_PORT', os.getpid())}")
     matcher.set_cursor(cursor.address)
-    matcher.set_chunks(int(os.environ.get("GPM_BENCH_CHUNKS", 64 * world)))
+    # Root chunks of equal estimated cost, shared by all ranks.  Finer chunks balance the ranks better at the
+    # end of a search but cost GPU time (smaller launches: 64 -> 191.6 ms, 128 -> 192.9, 256 -> 198.5,
+    # 512 -> 208.2 for the whole 4-clique search on one GPU), so the count grows more slowly than the ranks.
+    matcher.set_chunks(int(os.environ.get("GPM_BENCH_CHUNKS", 64 * world if world <= 2 else 32 * world)))
     # timed steps run without the byte accounting of the clique kernels (an add per adjacent pair inside the
     # kernels); the bytes, a property of the work, come from one more search after the timed region
     matcher.set_accounting(False)
@@ -315,7 +318,9 @@ def main():
     timing = {"on": False}
 
     def step():
-        gdist.reset_cursor(cursor)
+        # the all-reduce of the counts that ends every step is its only collective: the two cursor words
+        # alternate, so no barrier is needed around a reset
+        matcher.set_cursor(gdist.begin_step(cursor))
         local = matcher.findMatches(count_only=True)
         st = matcher.stats()  # HIP-event times of every launch, on the streams the kernels ran on
         if timing["on"]:
@@ -425,7 +430,7 @@ def main():
             "chunks_per_step_by_rank": [round(c / steps, 2) for c in taken],
             "collective": {"backend": backend if world > 1 else None,
                            "rccl": bool(world > 1 and backend == "nccl"),
-                           "per_step": "2 barriers around the cursor reset + 1 all-reduce of a 64-bit count" if world > 1 else "none"},
+                           "per_step": "1 all-reduce of a 64-bit count (two cursor words alternate: no barrier)" if world > 1 else "none"},
             "host_cores": host_cores()[0],
         }
         if world == 1 and not args.no_cpu_baseline:

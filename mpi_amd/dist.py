@@ -20,28 +20,36 @@ import torch.distributed as dist
 
 
 class SharedCursor:
-    """A zero-initialised 64-bit word in /dev/shm that every rank of the node maps."""
+    """Two zero-initialised 64-bit words (a cache line apart) in /dev/shm that every rank of the node maps.
+    `address` is the first word; searches that follow one another closely alternate between the two
+    (`begin_step`)."""
 
     def __init__(self, name: str, create: bool):
         self.path = os.path.join("/dev/shm", name)
         if create:
             with open(self.path, "wb") as f:
-                f.write(b"\0" * 64)
+                f.write(b"\0" * 128)
         self._f = open(self.path, "r+b")
-        self._map = mmap.mmap(self._f.fileno(), 64)
+        self._map = mmap.mmap(self._f.fileno(), 128)
         self._word = ctypes.c_uint64.from_buffer(self._map)
+        self._word1 = ctypes.c_uint64.from_buffer(self._map, 64)
         self.address = ctypes.addressof(self._word)
+        self.addresses = (self.address, ctypes.addressof(self._word1))
+        self.epoch = 0
         self._owner = create
 
     def reset(self):
         self._word.value = 0
+
+    def zero(self, which: int):
+        (self._word1 if which else self._word).value = 0
 
     @property
     def value(self):
         return self._word.value
 
     def close(self):
-        del self._word
+        del self._word, self._word1
         self._map.close()
         self._f.close()
         if self._owner and os.path.exists(self.path):
@@ -72,6 +80,20 @@ def reset_cursor(cur: SharedCursor):
     if dist.get_rank() == 0:
         cur.reset()
     dist.barrier()
+
+
+def begin_step(cur: SharedCursor) -> int:
+    """The address of the cursor word for the next search of a series in which EVERY search ends with a
+    collective all ranks join (the all-reduce of the counts).  No barrier is needed: search s takes its
+    chunks from word s mod 2, and rank 0 zeroes the other word before it starts search s.  That word last
+    served search s-1, which every rank had left before the collective that ended it completed; and no
+    rank starts search s+1 before the collective that ends search s, which rank 0 joins after the zeroing.
+    The first search finds word 0 zero as `open_cursor` left it."""
+    here = cur.epoch & 1
+    if not dist.is_initialized() or dist.get_rank() == 0:
+        cur.zero(here ^ 1)
+    cur.epoch += 1
+    return cur.addresses[here]
 
 
 def all_reduce_count(local_count: int, device="cpu") -> int:

@@ -88,9 +88,9 @@ def _timing_worker(rank, world, port, out_dir):
     calls = []
 
     def step():
-        gdist.reset_cursor(cur)
+        word = gdist.begin_step(cur)  # alternating cursor words, no barrier: as bench.py does
         mine = 0
-        while host.claimChunk(cur.address) < 10:  # ten chunks shared by the ranks
+        while host.claimChunk(word) < 10:  # ten chunks shared by the ranks
             mine += 1
             time.sleep(0.01 * (rank + 1))
         calls.append(mine)
