@@ -1740,11 +1740,13 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
         uint4 *dst = reinterpret_cast<uint4 *>(tile);
         constexpr int NT = NW * GPM_WAVE, FILL = 8;  // eight 16-byte reads in flight per thread
         for (int k0 = tid; k0 < nslots; k0 += FILL * NT) {
+            // every read is issued whatever k is (from a clamped address): values assigned under a condition
+            // would be kept in private memory, not in registers
             uint4 v[FILL];
 #pragma unroll
             for (int f = 0; f < FILL; ++f) {
-                const int k = k0 + f * NT, row = k >> lg, s4 = k & (L - 1);
-                if (k < nslots && s4 < Wq) v[f] = src[row * Wq + s4];
+                const int k = min(k0 + f * NT, nslots - 1), row = k >> lg, s4 = min(k & (L - 1), Wq - 1);
+                v[f] = src[row * Wq + s4];
             }
 #pragma unroll
             for (int f = 0; f < FILL; ++f) {
