@@ -36,6 +36,12 @@ struct GraphView {
     // whole list; membership tests keep using the id-ordered lists.
     const int32_t *adjL;
     const uint32_t *labseg;
+    // The arrays of one direction, chosen at run time.  A select between the two kernel arguments: indexing
+    // the pair with a run-time value makes the compiler keep a copy of it in private memory, and every
+    // membership test would start with a load from there.
+    __device__ __forceinline__ const int64_t *offs(int dir) const { return dir ? off[1] : off[0]; }
+    __device__ __forceinline__ const int32_t *adjs(int dir) const { return dir ? adj[1] : adj[0]; }
+    __device__ __forceinline__ const int64_t *mids(int dir) const { return dir ? mid[1] : mid[0]; }
 };
 
 __device__ __forceinline__ bool hub_arc(const GraphView &g, int32_t from, int32_t to) {
@@ -96,17 +102,19 @@ __device__ __forceinline__ int lower_bound_s(const int32_t *a, int b, int e, int
 __device__ __forceinline__ bool in_list(const GraphView &g, int dir, int part, int32_t v, int32_t c);
 
 __device__ __forceinline__ void list_range(const GraphView &g, int dir, int part, int32_t v, int64_t &b, int64_t &e) {
-    b = g.off[dir][v];
-    e = g.off[dir][v + 1];
-    if (part == PART_ABOVE) b = g.mid[dir][v];
-    else if (part == PART_BELOW) e = g.mid[dir][v];
+    // written with selects: two assignments under conditions get merged into one store at a run-time
+    // offset, which puts b and e into private memory
+    const int64_t lo = g.offs(dir)[v], hi = g.offs(dir)[v + 1];
+    const int64_t md = part == PART_FULL ? lo : g.mids(dir)[v];
+    b = part == PART_ABOVE ? md : lo;
+    e = part == PART_BELOW ? md : hi;
 }
 
 __device__ __forceinline__ bool in_list(const GraphView &g, int dir, int part, int32_t v, int32_t c) {
     if (v >= g.hub_base && c >= g.hub_base) return dir == 0 ? hub_arc(g, v, c) : hub_arc(g, c, v);
     int64_t b, e;
     list_range(g, dir, part, v, b, e);
-    return contains_g(g.adj[dir], b, e, c);
+    return contains_g(g.adjs(dir), b, e, c);
 }
 
 // Does this level draw its candidates from a label segment?
@@ -137,19 +145,19 @@ __device__ __forceinline__ void source_range(const GraphView &g, const LevelPlan
         if (hi != INT32_MAX) e = lower_bound_g(arr, b, e, hi);
         return;
     }
-    arr = g.adj[lv.src_dir];
+    arr = g.adjs(lv.src_dir);
     list_range(g, lv.src_dir, lv.src_part, m[lv.src_level], b, e);
     if (lv.n_lower && !lv.lower_is_src) {
         int32_t lo = -1;
         for (int j = 0; j < lv.n_lower; ++j)
             if (lv.lower_level[j] != skip_level) lo = max(lo, m[lv.lower_level[j]]);
-        if (lo >= 0) b = lower_bound_g(g.adj[lv.src_dir], b, e, lo + 1);
+        if (lo >= 0) b = lower_bound_g(g.adjs(lv.src_dir), b, e, lo + 1);
     }
     if (lv.n_upper) {
         int32_t hi = INT32_MAX;
         for (int j = 0; j < lv.n_upper; ++j)
             if (lv.upper_level[j] != skip_level) hi = min(hi, m[lv.upper_level[j]]);
-        if (hi != INT32_MAX) e = lower_bound_g(g.adj[lv.src_dir], b, e, hi);
+        if (hi != INT32_MAX) e = lower_bound_g(g.adjs(lv.src_dir), b, e, hi);
     }
 }
 
@@ -174,7 +182,7 @@ __device__ __forceinline__ void walk_range(const GraphView &g, const PlanView &p
         }
     }
     if (walk < 0) return;
-    arr = g.adj[lv.cons_dir[walk]];
+    arr = g.adjs(lv.cons_dir[walk]);
     int32_t lo = -1, hi = INT32_MAX;
     for (int j = 0; j < lv.n_lower; ++j) lo = max(lo, m[lv.lower_level[j]]);
     for (int j = 0; j < lv.n_upper; ++j) hi = min(hi, m[lv.upper_level[j]]);

@@ -175,7 +175,7 @@ __global__ void k_extend(GraphView g, PlanView pl, int k, const int32_t *rows, c
         const LevelPlan &lv = pl.lv[k];
         m = rows + lo * k;
         const int walk = wsel[lo];  // which operand list this row walks (see walk_range)
-        const int32_t *arr = walk >= 0 ? g.adj[lv.cons_dir[walk]] : from_segment(g, lv) ? g.adjL : g.adj[lv.src_dir];
+        const int32_t *arr = walk >= 0 ? g.adjs(lv.cons_dir[walk]) : from_segment(g, lv) ? g.adjL : g.adjs(lv.src_dir);
         c = arr[beg[lo] + (gi - pref[lo])];
         ok = accept(g, lv, m, k, c, walk);
     }
@@ -242,12 +242,12 @@ __device__ __forceinline__ uint32_t tail_reuse_count(const GraphView &g, const T
     uint32_t cnt = 0;
     int64_t b0, e0;
     list_range(g, ti.extra_dir[0], ti.extra_part[0], a, b0, e0);
-    const int32_t *adj0 = g.adj[ti.extra_dir[0]];
+    const int32_t *adj0 = g.adjs(ti.extra_dir[0]);
     int64_t b1 = 0, e1 = 0;
     const int32_t *adj1 = nullptr;
     if (ti.n_extra > 1) {
         list_range(g, ti.extra_dir[1], ti.extra_part[1], a, b1, e1);
-        adj1 = g.adj[ti.extra_dir[1]];
+        adj1 = g.adjs(ti.extra_dir[1]);
     }
     if ((int64_t)(se - sb) <= e0 - b0) {
         for (int i = sb + lane; i < se; i += GPM_WAVE) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
                 for (int j = 0; j < la.n_upper; ++j) hi_id = min(hi_id, m[la.upper_level[j]]);
             }
         }
-        const int32_t *wadj = walk < 0 ? sarr : g.adj[la.cons_dir[walk]];
+        const int32_t *wadj = walk < 0 ? sarr : g.adjs(la.cons_dir[walk]);
         if (walk >= 0 && e - b > GPM_WAVE) {  // a long list is entered and left at the bounds
             if (lo_id >= 0) b = lower_bound_g(wadj, b, e, lo_id + 1);
             if (hi_id != INT32_MAX) e = lower_bound_g(wadj, b, e, hi_id);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(TAIL_WAVES *GPM_WAVE) void k_tail(GraphView g, Plan
                 }
                 int32_t lo2 = -1, hi2 = INT32_MAX;
                 if (wb >= 0) {
-                    barr = g.adj[lb.cons_dir[wb]];
+                    barr = g.adjs(lb.cons_dir[wb]);
                     for (int j = 0; j < lb.n_lower; ++j)
                         if (lb.lower_level[j] != L) lo2 = max(lo2, m[lb.lower_level[j]]);
                     for (int j = 0; j < lb.n_upper; ++j)
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void k_tail_twin(GraphView g, PlanView pl, Tai
             for (int j = 0; j < la.n_lower; ++j) lo_id = max(lo_id, m[la.lower_level[j]]);
             for (int j = 0; j < la.n_upper; ++j) hi_id = min(hi_id, m[la.upper_level[j]]);
         }
-        const int32_t *wadj = walk < 0 ? sarr : g.adj[la.cons_dir[walk]];
+        const int32_t *wadj = walk < 0 ? sarr : g.adjs(la.cons_dir[walk]);
         if (walk >= 0 && e - b > 4 * G) {  // a long list is entered and left at the bounds
             if (lo_id >= 0) b = lower_bound_g(wadj, b, e, lo_id + 1);
             if (hi_id != INT32_MAX) e = lower_bound_g(wadj, b, e, hi_id);
