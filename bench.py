@@ -375,7 +375,7 @@ def main():
             share = (k_launches[dom] / steps) / max(int(sb.kernel_launches[dom]), 1)
         dom_bytes_per_step = k_bytes[dom] * share
         achieved = (dom_bytes_per_step * steps / 1e9) / (k_ms[dom] / 1e3) if k_ms[dom] > 0 else 0.0
-        traffic, traffic_note = None, "no committed counter pass"
+        traffic, traffic_note, tj = None, "no committed counter pass", {}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch from the committed PMC passes, per kernel family
             with open(tpath) as f:
@@ -384,11 +384,27 @@ def main():
                 traffic = tj.get(names[dom], {}).get("hbm_bytes_per_launch")
                 traffic_note = f"rocprofv3 counter passes, {tj.get('source', tpath)}"
             else:
+                tj = {}
                 traffic_note = "committed counter pass is of other kernel sources (stale): not reported"
-        families = {names[k]: {"ms_per_step": k_ms[k] / steps, "launches_per_step": k_launches[k] / steps,
-                               "alg_GB_per_search": k_bytes[k] / 1e9}
-                    for k in range(kinds) if k_launches[k]}
+        avg_ms = k_ms[dom] / max(k_launches[dom], 1)
+        # the same figures for every family: algorithmic rate (merge model) and, where the committed counter
+        # passes are of these kernel sources, the rate of the bytes HBM really moved per launch
+        families = {}
+        for k in range(kinds):
+            if not k_launches[k]:
+                continue
+            fam = {"ms_per_step": k_ms[k] / steps, "launches_per_step": k_launches[k] / steps,
+                   "alg_GB_per_search": k_bytes[k] / 1e9}
+            if k_ms[k] > 0 and k_bytes[k]:
+                fam["alg_GBps"] = (k_bytes[k] * (share if k == dom else 1.0) / 1e9) / (k_ms[k] / steps / 1e3)
+            t = tj.get(names[k], {}).get("hbm_bytes_per_launch")
+            if t is not None and k_ms[k] > 0:
+                fam["hbm_GB_per_launch"] = t / 1e9
+                fam["hbm_GBps"] = (t / 1e9) / (k_ms[k] / k_launches[k] / 1e3)
+            families[names[k]] = fam
         want, want_src = expected_count(args.config, cfg, overridden, labelled)
+        if os.environ.get("GPM_EMULATE_RANKS"):  # this process takes every N-th chunk only: a share, not the count
+            want, want_src = None, "one emulated rank's share of the chunks (GPM_EMULATE_RANKS): no expected count"
         line = {
             "metric": "pattern matches found/sec and wall time, R-MAT scale-24 4-clique at 1/2/4/8 GPUs",
             "value": total / sec_per_step,
@@ -415,9 +431,14 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_from": traffic_note,
                          "alg_bytes_per_launch": dom_bytes_per_step * steps / max(k_launches[dom], 1),
-                         "avg_launch_ms": k_ms[dom] / max(k_launches[dom], 1), "launches": k_launches[dom],
+                         "avg_launch_ms": avg_ms, "launches": k_launches[dom],
+                         "traffic_GBps": None if traffic is None or avg_ms <= 0 else (traffic / 1e9) / (avg_ms / 1e3),
+                         "traffic_frac": None if traffic is None or avg_ms <= 0 else (traffic / 1e9) / (avg_ms / 1e3) / HBM_PEAK_GBS,
                          "note": "time: HIP events around every launch of the family inside the timed steps; bytes: "
-                                 "merge-model bytes of the same work, summed on the device in one more search"},
+                                 "merge-model bytes of the same work, summed on the device in one more search. "
+                                 "frac above 1 means the kernel moves fewer bytes than the merge model streams "
+                                 "(hub-matrix bits and LDS bitmaps instead of list passes); traffic_frac is the "
+                                 "rate of the bytes HBM really moved"},
             "kernel_families_rank0": families,
             "one_chunk_in_flight": None if alone is None else {
                 "note": "one extra search outside the timed region with launches not overlapping",

@@ -177,9 +177,12 @@ struct DevState {
     int clq_scratch_blocks = 0;
     int clq_probe_bias = 0;    // GPM_CLIQUE_PROBE_BIAS, read once per context
     bool count4_wide = true;   // GPM_COUNT4_WAVES >= 16
-    int clq_lists_max_class = 2;  // GPM_CLQ_LISTS_MAX_CLASS: size classes up to this one build their rows from the
+    int clq_lists_max_class = 5;  // GPM_CLQ_LISTS_MAX_CLASS: size classes up to this one build their rows from the
                                   // adjacency lists, larger ones from hub-matrix gathers (1 = gathers only)
     int clq_build_rb = 0;         // GPM_CLQ_BUILD_RB: workgroups per root of that kernel (0 = by size class)
+    int clq_lists_waves = 16;     // GPM_CLQ_LISTS_WAVES: waves per workgroup of that kernel (4 or 16)
+    int clq_kappa4 = 6;           // GPM_CLQ_KAPPA4: a row of that kernel whose list has this many quarter entries per
+                                  // position left to test is gathered from the hub matrix instead (-1: never)
     unsigned long long *clq_slots = nullptr;  // [0,CLQ_SLOTS) matches, [CLQ_SLOTS,2*CLQ_SLOTS) bytes
     // 4-cycle path: two-path count of every root, counter arrays (cyc_blocks of them for the workgroups of
     // the light kernel, then CYC_HEAVY_GROUPS groups of cyc_batch for heavy roots), root queues of the light
@@ -552,8 +555,10 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     for (auto &d : ctx->devs) {
         d.clq_probe_bias = (int)env_i64("GPM_CLIQUE_PROBE_BIAS", 0);
         d.count4_wide = env_i64("GPM_COUNT4_WAVES", 16) >= 16;
-        d.clq_lists_max_class = (int)env_i64("GPM_CLQ_LISTS_MAX_CLASS", 2);
+        d.clq_lists_max_class = (int)env_i64("GPM_CLQ_LISTS_MAX_CLASS", 5);
         d.clq_build_rb = (int)env_i64("GPM_CLQ_BUILD_RB", 0);
+        d.clq_lists_waves = env_i64("GPM_CLQ_LISTS_WAVES", 16) == 4 ? 4 : 16;
+        d.clq_kappa4 = (int)env_i64("GPM_CLQ_KAPPA4", 6);
     }
     // GPM_NO_RCCL=1: per-GPU counts are summed on the host only (also lets two workers share one GPU in tests)
     if ((ngpus > 1 && env_i64("GPM_NO_RCCL", 0) == 0) || env_i64("GPM_FORCE_RCCL", 0)) {
@@ -1894,11 +1899,19 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CL
             if (ALL_HUB && !STATS && c <= d.clq_lists_max_class && bm_words <= CLQ_BM_MAX_WORDS) {
                 // rows from the adjacency lists, tested against a bitmap of the universe in LDS
                 const int RB = d.clq_build_rb > 0 ? d.clq_build_rb : (c == 2 ? 1 : c == 3 ? 2 : c == 4 ? 4 : 8);
-                const size_t lds_lists = ((size_t)bm_words + bm_words / 2 + dcap + 4 * 128) * sizeof(uint32_t);
-                HIP_TRY(hipFuncSetAttribute((const void *)k_clq_build_lists<K>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists));
-                k_clq_build_lists<K><<<(unsigned)(nb * RB), 256, lds_lists, s>>>(d.gv, list + b0, nb, dcap, RB, base_id,
-                                                                              bm_words, sl.rows, stride, cnt);
+                const int nwl = d.clq_lists_waves;
+                const size_t lds_lists = ((size_t)bm_words + bm_words / 2 + dcap + (size_t)nwl * 128) * sizeof(uint32_t);
+                if (nwl == 16) {
+                    HIP_TRY(hipFuncSetAttribute((const void *)k_clq_build_lists<K, 16>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists));
+                    k_clq_build_lists<K, 16><<<(unsigned)(nb * RB), 1024, lds_lists, s>>>(
+                        d.gv, list + b0, nb, dcap, RB, base_id, bm_words, d.clq_kappa4, sl.rows, stride, cnt);
+                } else {
+                    HIP_TRY(hipFuncSetAttribute((const void *)k_clq_build_lists<K, 4>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists));
+                    k_clq_build_lists<K, 4><<<(unsigned)(nb * RB), 256, lds_lists, s>>>(
+                        d.gv, list + b0, nb, dcap, RB, base_id, bm_words, d.clq_kappa4, sl.rows, stride, cnt);
+                }
             } else {
                 if (lds_build > 48 * 1024)
                     HIP_TRY(hipFuncSetAttribute((const void *)k_clq_build<K, STATS, ALL_HUB>,

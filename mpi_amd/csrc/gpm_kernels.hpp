@@ -1500,20 +1500,30 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
 // the lowest root of the chunk as base_id (universes only hold vertices above
 // their root) and sizes the LDS for it.
 //
-// grid = nroots * RB workgroups of 256 threads; workgroup (ri, rb) builds the
-// rows i = rb (mod RB) of root ri, its four waves taking them in turn.  The
+// grid = nroots * RB workgroups of NW waves; workgroup (ri, rb) builds the
+// rows i = rb (mod RB) of root ri, its waves taking them in turn.  The bitmap
+// and its prefix counts take up to 96 KiB, so one workgroup fits a compute unit
+// whatever its size: NW = 16 gives the unit 16 waves to stream lists with.  The
 // list ranges of 64 rows are fetched at once (one row per lane); a row's first
 // 512 entries are in flight while the row before it is tested.
-// LDS (words): bitmap[bm_words] | prefix[bm_words / 2] (16-bit) | U[dcap] | stage[4][128].
+//
+// Rows near the end of a universe belong to its highest-degree vertices: long
+// lists, and few positions above the row left to test.  A row whose list holds
+// at least `kappa4` / 4 entries per position above it is gathered from the hub
+// matrix instead (every vertex of the launch's universes is a hub), one bit
+// per position; kappa4 < 0: never.
+// LDS (words): bitmap[bm_words] | prefix[bm_words / 2] (16-bit) | U[dcap] | stage[NW][128].
 #define CLQ_BM_MAX_WORDS 16384  // ids a bitmap can cover: 2^19
 #define CLQ_LIST_LOADS 8        // list reads in flight per lane and row
 
-template <int K>
-__global__ __launch_bounds__(256) void k_clq_build_lists(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
-                                                         int RB, int32_t base_id, int bm_words, uint32_t *rows_buf,
-                                                         int64_t stride_words, unsigned long long *n_matches) {
+template <int K, int NW>
+__global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, const int32_t *roots, int64_t nroots,
+                                                                 int dcap, int RB, int32_t base_id, int bm_words,
+                                                                 int kappa4, uint32_t *rows_buf, int64_t stride_words,
+                                                                 unsigned long long *n_matches) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    __shared__ uint32_t s_wave_sum[4];
+    __shared__ uint32_t s_wave_sum[NW];
+    constexpr int NT = NW * GPM_WAVE;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
     const int64_t ri = blockIdx.x / RB;
     const int rb = (int)(blockIdx.x % RB);
@@ -1528,9 +1538,9 @@ __global__ __launch_bounds__(256) void k_clq_build_lists(GraphView g, const int3
     uint16_t *prefix = reinterpret_cast<uint16_t *>(smem + bm_words);     // set bits before each bitmap word
     int32_t *U = (int32_t *)(smem + bm_words + bm_words / 2);
     uint32_t *stage = smem + bm_words + bm_words / 2 + dcap + wave * 128;
-    for (int k = tid; k < bm_words / 4; k += 256) reinterpret_cast<uint4 *>(bm)[k] = make_uint4(0u, 0u, 0u, 0u);
+    for (int k = tid; k < bm_words / 4; k += NT) reinterpret_cast<uint4 *>(bm)[k] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    for (int i = tid; i < d; i += 256) {
+    for (int i = tid; i < d; i += NT) {
         const int32_t v = adj[ub + i];
         U[i] = v;
         const uint32_t c = (uint32_t)(v - base_id);
@@ -1538,7 +1548,7 @@ __global__ __launch_bounds__(256) void k_clq_build_lists(GraphView g, const int3
     }
     __syncthreads();
     {  // prefix counts: every thread sums its run of words, the runs are scanned, the words filled in
-        const int wpt = bm_words / 256;
+        const int wpt = bm_words / NT;  // bm_words is a multiple of 1024
         uint32_t mine = 0;
         for (int k = 0; k < wpt; ++k) mine += __popc(bm[tid * wpt + k]);
         uint32_t incl = mine;
@@ -1560,10 +1570,10 @@ __global__ __launch_bounds__(256) void k_clq_build_lists(GraphView g, const int3
     const int T = big_tiles(d);
     uint32_t *region = rows_buf + ri * stride_words;
     uint64_t tri = 0;
-    const int step = 4 * RB;               // distance between two rows of one wave
+    const int step = NW * RB;              // distance between two rows of one wave
     const int first = rb + RB * wave;      // this wave's first row
     for (int i_batch = first; i_batch < d; i_batch += 64 * step) {
-        // list ranges of the next 64 rows of this wave, one row per lane
+        // list ranges of the next 64 rows of this wave, one row per lane; n = -1: the row is gathered
         int64_t my_b = 0;
         int my_n = 0;
         {
@@ -1572,6 +1582,7 @@ __global__ __launch_bounds__(256) void k_clq_build_lists(GraphView g, const int3
                 const int32_t v = U[i_l];
                 my_b = mid[v];
                 my_n = (int)(off[v + 1] - my_b);
+                if (kappa4 >= 0 && (int64_t)(d - 1 - i_l) * kappa4 <= 4 * (int64_t)my_n) my_n = -1;
             }
         }
         const uint32_t my_b_lo = (uint32_t)my_b, my_b_hi = (uint32_t)((uint64_t)my_b >> 32);
@@ -1616,6 +1627,38 @@ __global__ __launch_bounds__(256) void k_clq_build_lists(GraphView g, const int3
                     atomicOr(stage + (j >> 5), 1u << (j & 31));
                 }
             };
+            if (n < 0) {  // a row of few positions and a long list: one hub-matrix bit per position above it
+                const uint32_t *hrow = g.hub + (size_t)(U[i] - g.hub_base) * (size_t)g.hub_wpr;
+                const int jfirst = ((i + 1) / (CLQ_GATHERS * GPM_WAVE)) * (CLQ_GATHERS * GPM_WAVE);
+                for (int j0 = jfirst; j0 < d; j0 += CLQ_GATHERS * GPM_WAVE) {
+                    uint32_t word[CLQ_GATHERS], sh[CLQ_GATHERS];
+                    bool live[CLQ_GATHERS];
+#pragma unroll
+                    for (int k = 0; k < CLQ_GATHERS; ++k) {
+                        const int j = j0 + k * GPM_WAVE + lane;
+                        live[k] = j > i && j < d;
+                        word[k] = 0;
+                        sh[k] = 0;
+                        if (live[k]) {
+                            const uint32_t c = (uint32_t)(U[j] - g.hub_base);
+                            word[k] = hrow[c >> 5];
+                            sh[k] = c & 31;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < CLQ_GATHERS; ++k) {
+                        const int jb = j0 + k * GPM_WAVE;
+                        if (jb >= d) break;
+                        const bool bit = live[k] && ((word[k] >> sh[k]) & 1u);
+                        const unsigned long long mask = __ballot(bit);
+                        if (K == 3) tri += bit;
+                        if (K != 3 && lane == 0) {  // the stage has room for 4096 positions: jb + 63 < 4096
+                            stage[jb >> 5] = (uint32_t)mask;
+                            stage[(jb >> 5) + 1] = (uint32_t)(mask >> 32);
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < CLQ_LIST_LOADS; ++k) test(cur[k]);
             for (int p0 = CLQ_LIST_LOADS * GPM_WAVE; p0 < n; p0 += 4 * GPM_WAVE) {  // the rest of a long list

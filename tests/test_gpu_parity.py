@@ -124,11 +124,16 @@ LARGE_PATHS = {
                 # universes above 24 vertices through the build / count pair: rows gathered from the hub matrix ...
                 ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_MAX_CLASS": "1"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
                 ({"GPM_CLIQUE_SMALL_MAX": "24"}, True, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
-                # ... and built from the adjacency lists
-                ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_MAX_CLASS": "5"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
+                # ... built from the adjacency lists alone, by gathers inside the list kernel alone, and by the
+                # default mixture (long lists with few positions left are gathered), four waves per workgroup
+                ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_KAPPA4": "-1"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
+                ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_KAPPA4": "0"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
+                ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_WAVES": "4"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
                 ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_COUNT4_WAVES": "8"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT))],
     "triangle": [({}, True, ()), ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_MAX_CLASS": "1"}, False, (KIND_CLQ_BUILD,)),
-                 ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_MAX_CLASS": "5"}, False, (KIND_CLQ_BUILD,))],
+                 ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_KAPPA4": "-1"}, False, (KIND_CLQ_BUILD,)),
+                 ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_KAPPA4": "0"}, False, (KIND_CLQ_BUILD,)),
+                 ({"GPM_CLIQUE_SMALL_MAX": "24"}, False, (KIND_CLQ_BUILD,))],
     "cycle4": [({}, True, (KIND_CYCLE4,)), ({"GPM_CYCLE4_HEAVY": "4096"}, True, (KIND_CYCLE4,))],
 }
 
@@ -142,7 +147,8 @@ def test_large_goldens(spec, monkeypatch):
     n, s, d = util.build_graph(spec)
     dl, pl = util.build_labels(spec, n)
     for env, accounting, kinds in LARGE_PATHS.get(spec["pattern"], [({}, True, ())]):
-        for k in ("GPM_CLIQUE_SMALL_MAX", "GPM_CLQ_LISTS_MAX_CLASS", "GPM_COUNT4_WAVES", "GPM_CYCLE4_HEAVY"):
+        for k in ("GPM_CLIQUE_SMALL_MAX", "GPM_CLQ_LISTS_MAX_CLASS", "GPM_COUNT4_WAVES", "GPM_CYCLE4_HEAVY", "GPM_CLQ_KAPPA4",
+                  "GPM_CLQ_LISTS_WAVES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
