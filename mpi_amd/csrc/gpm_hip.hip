@@ -236,6 +236,7 @@ struct gpm_ctx {
     bool fuse3_wave = true, fuse3_mid = true, trace = false;
     int clique_max_d_env = -1;   // GPM_CLIQUE_MAX_D, -1 = unset
     int clique_small_max = 256;  // GPM_CLIQUE_SMALL_MAX
+    int clique_tiny = 32;        // GPM_CLIQUE_TINY: largest universe of the lane-group kernel (0, 16, 32 or 64)
     int64_t cyc_heavy_block = 2048, cyc_span = (int64_t)1 << 18;
     int64_t cyc_heavy_thr = 0;             // two-paths from which a root is cut into spans (k_cycle4_heavy)
     std::vector<int64_t> cyc_heavy_roots;  // root indices at or above the threshold, ascending
@@ -550,6 +551,10 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->trace = getenv("GPM_TRACE") != nullptr;
     ctx->clique_max_d_env = (int)env_i64("GPM_CLIQUE_MAX_D", -1);
     ctx->clique_small_max = (int)std::min<int64_t>(256, std::max<int64_t>(4, env_i64("GPM_CLIQUE_SMALL_MAX", 256)));
+    {
+        const int64_t t = env_i64("GPM_CLIQUE_TINY", 32);
+        ctx->clique_tiny = t >= 64 ? 64 : t >= 32 ? 32 : t >= 16 ? 16 : 0;
+    }
     ctx->cyc_heavy_block = std::max<int64_t>(256, env_i64("GPM_CYC_HEAVY_BLOCK", 2048)) / 256 * 256;
     ctx->cyc_span = std::max<int64_t>(1, env_i64("GPM_CYC_SPAN", (int64_t)1 << 18) / ctx->cyc_heavy_block) * ctx->cyc_heavy_block;
     for (auto &d : ctx->devs) {
@@ -1266,7 +1271,7 @@ static int ensure_buffers(gpm_ctx *ctx, DevState &d, bool count_only) {
         for (auto &sl : d.slots) {
             HIP_TRY(hipMalloc(&sl.lists, (size_t)CLQ_CLASSES * (size_t)d.clq_stride * sizeof(int32_t)));
             HIP_TRY(hipMalloc(&sl.rows, (size_t)CLQ_ROWS_WORDS * sizeof(uint32_t)));
-            HIP_TRY(hipMalloc(&sl.counts, 8 * sizeof(unsigned long long)));
+            HIP_TRY(hipMalloc(&sl.counts, 16 * sizeof(unsigned long long)));
         }
         d.clq_scratch_blocks = (int)env_i64("GPM_CLIQUE_SCRATCH_BLOCKS", 512);
         for (auto &sl : d.slots)
@@ -1984,6 +1989,21 @@ static int clique_launch(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CLASSE
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d, s))) return rc;
     }
+    if constexpr (K == 3 || K == 4) {
+        // universes of at most 64, 32, 16 vertices: a group of that many lanes per root, rows in registers
+#define TINY_LAUNCH(CLS, GG)                                                                                          \
+    if (n[CLS]) {                                                                                                     \
+        if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[CLS], s, CLS))) return rc;                               \
+        const unsigned blocks = (unsigned)(((uint64_t)n[CLS] + 256 / GG - 1) / (256 / GG));                          \
+        k_clique_tiny<K, GG, STATS><<<blocks, 256, 0, s>>>(d.gv, l + (int64_t)(CLS) * st, (int64_t)n[CLS], cnt, byt); \
+        HIP_TRY(hipGetLastError());                                                                                   \
+        if ((rc = timed_end(d, s))) return rc;                                                                        \
+    }
+        TINY_LAUNCH(CLQ_TINY + 2, 64)
+        TINY_LAUNCH(CLQ_TINY + 1, 32)
+        TINY_LAUNCH(CLQ_TINY, 16)
+#undef TINY_LAUNCH
+    }
     if (n[0]) {
         if ((rc = timed_begin(d, GPM_KIND_CLIQUE, (int64_t)n[0], s, 0))) return rc;
         k_clique<K, 64, true, STATS><<<(unsigned)n[0], 64, clq_lds_bytes(K, 64, 64, true), s>>>(d.gv, l, (int64_t)n[0], 64, bias,
@@ -2007,6 +2027,11 @@ static int clique_max_d(const gpm_ctx *ctx) {
 // those kernels.
 static int clique_small_max(const gpm_ctx *ctx) { return ctx->clique_k > 4 ? 256 : ctx->clique_small_max; }
 
+// Largest universe of the lane-group kernel (triangles and 4-cliques), 0 when it is not used.
+static int clique_tiny_max(const gpm_ctx *ctx) {
+    return ctx->clique_k <= 4 ? std::min(ctx->clique_tiny, clique_small_max(ctx)) : 0;
+}
+
 // One chunk of roots through the bitmap kernel, enqueued on the slot's stream
 // without any host round trip: the per-class root counts come from the chunk
 // table.  Roots whose N+ exceeds the kernel's universe (class 4) go through
@@ -2014,11 +2039,12 @@ static int clique_small_max(const gpm_ctx *ctx) { return ctx->clique_k > 4 ? 256
 static int clique_chunk(const SearchArgs &a, DevState &d, ChunkSlot &sl, const Chunk &ch) {
     gpm_ctx *ctx = a.ctx;
     hipStream_t s = sl.stream;
-    HIP_TRY(hipMemsetAsync(sl.counts, 0, 8 * sizeof(unsigned long long), s));
-    k_clique_bin<<<grid_for(ch.hi - ch.lo), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx), clique_small_max(ctx), ch.lo, ch.hi, sl.lists,
+    HIP_TRY(hipMemsetAsync(sl.counts, 0, 16 * sizeof(unsigned long long), s));
+    k_clique_bin<<<grid_for(ch.hi - ch.lo), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx), clique_small_max(ctx), clique_tiny_max(ctx), ch.lo, ch.hi, sl.lists,
                                                          d.clq_stride, sl.counts);
     HIP_TRY(hipGetLastError());
-    d.rows_in[0] += (uint64_t)ch.n[0] + ch.n[1] + ch.n[2] + ch.n[3] + ch.n[4] + ch.n[5];
+    d.rows_in[0] += (uint64_t)ch.n[0] + ch.n[1] + ch.n[2] + ch.n[3] + ch.n[4] + ch.n[5] + ch.n[CLQ_TINY] +
+                    ch.n[CLQ_TINY + 1] + ch.n[CLQ_TINY + 2];
     int rc = GPM_OK;
     // roots run from vertex n-1-lo down to n-hi; universes only hold higher vertices
     const bool all_hub = d.gv.hub != nullptr && (int64_t)ctx->info.n - ch.hi >= (int64_t)d.gv.hub_base;
@@ -2034,7 +2060,7 @@ static int clique_chunk(const SearchArgs &a, DevState &d, ChunkSlot &sl, const C
         default: return fail(GPM_ERUNTIME, "clique size %d not supported", ctx->clique_k);
     }
     if (rc) return rc;
-    const int generic = CLQ_CLASSES - 1;  // roots too large for the bitmap kernels
+    const int generic = CLQ_GENERIC;  // roots too large for the bitmap kernels
     if (ch.n[generic]) {
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipMemcpyAsync(d.F[0], sl.lists + (int64_t)generic * d.clq_stride,
@@ -2164,7 +2190,7 @@ static int prepare_chunks(gpm_ctx *ctx) {
         unsigned int *table = table_buf.as<unsigned int>();
         HIP_TRY(hipMemcpyAsync(dbounds, bounds.data(), (size_t)nch * sizeof(int64_t), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemsetAsync(table, 0, (size_t)nch * CLQ_CLASSES * sizeof(unsigned int), s));
-        k_chunk_classes<<<grid_for(nroots), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx), clique_small_max(ctx), lo, hi, dbounds, nch,
+        k_chunk_classes<<<grid_for(nroots), 256, 0, s>>>(d.gv, ctx->clique_k, clique_max_d(ctx), clique_small_max(ctx), clique_tiny_max(ctx), lo, hi, dbounds, nch,
                                                          table);
         std::vector<unsigned int> htable((size_t)nch * CLQ_CLASSES);
         HIP_TRY(hipMemcpyAsync(htable.data(), table, htable.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, s));

@@ -940,12 +940,17 @@ __global__ void k_hub_fill(GraphView g, uint32_t *bits) {
 #define CLQ_GATHERS 4                  // independent hub-matrix gathers in flight per lane
 #endif
 #define CLQ_SLOTS 1024                 // result counters are spread over this many slots
-#define CLQ_CLASSES 7
+#define CLQ_CLASSES 10
+#define CLQ_GENERIC 6                  // class of the roots too large for the bitmap kernels
+#define CLQ_TINY 7                     // classes 7, 8, 9: universe fits a group of 16, 32, 64 lanes
+#define CLQ_TINY_G 16
 
 // small_max: largest universe of the kernels that keep their rows in LDS (256; tests lower it to send
 // small universes through the build / count kernel pair).
-__device__ __forceinline__ int clq_class(int64_t d, int max_d, int small_max) {
-    return d > max_d ? CLQ_CLASSES - 1
+// tiny_max: largest universe of the lane-group kernel (16, 32 or 64, or 0 when it is not used).
+__device__ __forceinline__ int clq_class(int64_t d, int max_d, int small_max, int tiny_max) {
+    return d > max_d ? CLQ_GENERIC
+         : d <= tiny_max ? (d <= 16 ? CLQ_TINY : d <= 32 ? CLQ_TINY + 1 : CLQ_TINY + 2)
          : d <= min(64, small_max) ? 0 : d <= small_max ? 1 : d <= 512 ? 2 : d <= 1024 ? 3 : d <= 2048 ? 4 : 5;
 }
 
@@ -953,15 +958,16 @@ __device__ __forceinline__ int clq_class(int64_t d, int max_d, int small_max) {
 // compacted list (ballot + prefix popcount, one atomic per wave and class).
 //   class 0: K-1 <= d <= 64   1: d <= 256   2: d <= 512   3: d <= 1024
 //   4: d <= 2048   5: d <= 4096 (classes 4, 5 only up to max_d)   6: larger (generic path)
-__global__ void k_clique_bin(GraphView g, int K, int max_d, int small_max, int64_t lo, int64_t hi, int32_t *lists,
-                             int64_t list_stride, unsigned long long *counts) {
+//   7, 8, 9: d <= 16, 32, 64 where d <= tiny_max (taken out of classes 0 and 1)
+__global__ void k_clique_bin(GraphView g, int K, int max_d, int small_max, int tiny_max, int64_t lo, int64_t hi,
+                             int32_t *lists, int64_t list_stride, unsigned long long *counts) {
     int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int cls = -1;
     int32_t v = 0;
     if (i < hi) {
         v = (int32_t)(g.n - 1 - i);
         int64_t d = g.off[0][v + 1] - g.mid[0][v];
-        if (d >= K - 1) cls = clq_class(d, max_d, small_max);
+        if (d >= K - 1) cls = clq_class(d, max_d, small_max, tiny_max);
     }
     int lane = lane_id();
     for (int c = 0; c < CLQ_CLASSES; ++c) {
@@ -987,14 +993,14 @@ __global__ void k_root_cost(GraphView g, int oriented, int min_d, int64_t lo, in
 }
 
 // Size-class histogram of the roots of every chunk (the classes of k_clique_bin).
-__global__ void k_chunk_classes(GraphView g, int K, int max_d, int small_max, int64_t lo, int64_t hi, const int64_t *bounds,
-                                int nchunks, unsigned int *table) {
+__global__ void k_chunk_classes(GraphView g, int K, int max_d, int small_max, int tiny_max, int64_t lo, int64_t hi,
+                                const int64_t *bounds, int nchunks, unsigned int *table) {
     int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hi) return;
     int32_t v = (int32_t)(g.n - 1 - i);
     int64_t d = g.off[0][v + 1] - g.mid[0][v];
     if (d < K - 1) return;
-    int cls = clq_class(d, max_d, small_max);
+    int cls = clq_class(d, max_d, small_max, tiny_max);
     int a = 0, b = nchunks;  // last chunk whose first root is <= i
     while (b - a > 1) {
         int m = (a + b) >> 1;
@@ -1298,6 +1304,119 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
     if (lane == 0) {
         if (total) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)total);
         if (bytes) atomicAdd(alg_bytes + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)bytes);
+    }
+}
+
+// Triangles / 4-cliques of roots whose universe has at most G = 16, 32 or 64 vertices -- most roots of
+// a power-law graph.  A wave per root with its rows in LDS would leave most lanes idle and spend its
+// time on per-root set-up; here a group of G lanes takes a root and everything stays in registers:
+// lane i holds U[i] and builds row i = the positions j > i with U[i] -> U[j] (one hub-matrix bit, or one
+// binary search in N+(U[i]) per pair, four pairs in flight; the other vertex is fetched from its lane),
+// then adds |row_i ^ row_j| over the set bits j of its row, rows again fetched from their lanes.
+// grid = ceil(nroots / (256 / G)) workgroups of 256 threads.
+// STATS: also the merge-model bytes of the three levels, as k_clique sums them.
+template <int G>
+struct TinyRow { typedef uint32_t type; };
+template <>
+struct TinyRow<64> { typedef uint64_t type; };
+
+template <int K, int G, bool STATS>
+__global__ __launch_bounds__(256) void k_clique_tiny(GraphView g, const int32_t *roots, int64_t nroots,
+                                                     unsigned long long *n_matches, unsigned long long *alg_bytes) {
+    static_assert(K == 3 || K == 4, "lane-group kernel exists for triangles and 4-cliques");
+    typedef typename TinyRow<G>::type row_t;
+    const int lane = lane_id(), sub = lane & (G - 1), base = lane & ~(G - 1);
+    const int64_t ri = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t *off = g.off[0], *mid = g.mid[0];
+    const int32_t *adj = g.adj[0];
+    int d = 0;
+    int32_t my_v = -1;
+    int64_t my_b = 0, my_e = 0;
+    if (ri < nroots) {
+        const int32_t u = roots[ri];
+        const int64_t ub = mid[u];
+        d = (int)(off[u + 1] - ub);
+        if (sub < d) {
+            my_v = adj[ub + sub];
+            my_b = mid[my_v];
+            my_e = off[my_v + 1];
+        }
+    }
+    int dmax = d;  // the largest universe among the groups of this wave bounds the loops
+    if (G <= 32) dmax = max(dmax, __shfl_xor(dmax, 32, GPM_WAVE));
+    if (G <= 16) dmax = max(dmax, __shfl_xor(dmax, 16, GPM_WAVE));
+    const bool my_hub = my_v >= g.hub_base;  // then every vertex above it is a hub as well
+    const uint32_t *hrow = my_hub ? g.hub + (size_t)(my_v - g.hub_base) * (size_t)g.hub_wpr : nullptr;
+    const uint32_t my_dp = (uint32_t)(my_e - my_b);
+    const uint64_t per_arc = 12ull + 4ull * ((uint64_t)d + my_dp);
+    uint64_t bytes = 0;
+    if (STATS && sub < d) bytes = 8ull + 4ull * ((uint64_t)d + my_dp) + (sub == 0 ? 4ull + 4ull * (uint64_t)d : 0ull);
+    row_t row = 0;
+    for (int j0 = 1; j0 < dmax; j0 += 4) {  // four probes in flight per lane
+        int32_t w[4];
+        uint32_t word[4], dpw[4];
+        bool live[4], in[4];
+        int64_t sb[4], se[4];  // binary searches of the lanes whose vertex is not a hub, advanced together
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + k;
+            w[k] = __shfl(my_v, base + (j & (G - 1)), GPM_WAVE);
+            dpw[k] = STATS ? (uint32_t)__shfl((int)my_dp, base + (j & (G - 1)), GPM_WAVE) : 0u;
+            live[k] = j < G && j > sub && j < d;
+            word[k] = 0;
+            if (live[k] && my_hub) word[k] = hrow[(uint32_t)(w[k] - g.hub_base) >> 5];
+            const bool srch = live[k] && !my_hub;
+            sb[k] = srch ? my_b : 0;
+            se[k] = srch ? my_e : 0;
+        }
+        while ((sb[0] < se[0]) | (sb[1] < se[1]) | (sb[2] < se[2]) | (sb[3] < se[3])) {
+            int32_t x[4];
+            int64_t m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                m[k] = sb[k] + ((se[k] - sb[k]) >> 1);
+                x[k] = sb[k] < se[k] ? adj[m[k]] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (sb[k] < se[k]) {
+                    if (x[k] < w[k]) sb[k] = m[k] + 1;
+                    else se[k] = m[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            in[k] = false;
+            if (!live[k]) continue;
+            // a search ends on the first entry >= w[k], if there is one
+            in[k] = my_hub ? (word[k] >> ((uint32_t)(w[k] - g.hub_base) & 31)) & 1u
+                           : (sb[k] < my_e && adj[sb[k]] == w[k]);
+            row |= (row_t)in[k] << (j0 + k);
+            if (STATS && K >= 4 && in[k]) bytes += per_arc + 4ull * dpw[k];
+        }
+    }
+    uint32_t acc = 0;
+    if (K == 3) {
+        acc = G == 64 ? (uint32_t)__popcll((uint64_t)row) : (uint32_t)__popc((uint32_t)row);
+    } else {
+        for (int j = 1; j < dmax; ++j) {
+            row_t rj;
+            if (G == 64) {
+                const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)row, base + j, GPM_WAVE);
+                const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)((uint64_t)row >> 32), base + j, GPM_WAVE);
+                rj = (row_t)(((uint64_t)hi << 32) | lo);
+            } else {
+                rj = (row_t)(uint32_t)__shfl((int)(uint32_t)row, base + (j & (G - 1)), GPM_WAVE);
+            }
+            if ((row >> j) & 1u) acc += G == 64 ? (uint32_t)__popcll((uint64_t)(row & rj)) : (uint32_t)__popc((uint32_t)(row & rj));
+        }
+    }
+    const uint64_t total = wave_sum_u64((uint64_t)acc);
+    if (STATS) bytes = wave_sum_u64(bytes);
+    if (lane == 0) {
+        if (total) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)total);
+        if (STATS && bytes) atomicAdd(alg_bytes + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)bytes);
     }
 }
 

@@ -121,6 +121,9 @@ KIND_CLQ_BUILD, KIND_CLQ_COUNT, KIND_CYCLE4 = 3, 4, 5  # GPM_KIND_* of include/g
 # device paths a large vector is run through: (environment, accounting on, kernel families that must have run)
 LARGE_PATHS = {
     "clique4": [({}, True, ()), ({}, False, ()),
+                # small universes: rows in LDS only, or in the registers of lane groups up to a whole wave
+                ({"GPM_CLIQUE_TINY": "0"}, False, ()), ({"GPM_CLIQUE_TINY": "64"}, False, ()),
+                ({"GPM_CLIQUE_TINY": "64"}, True, ()),
                 # universes above 24 vertices through the build / count pair: rows gathered from the hub matrix ...
                 ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_MAX_CLASS": "1"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
                 ({"GPM_CLIQUE_SMALL_MAX": "24"}, True, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
@@ -130,7 +133,8 @@ LARGE_PATHS = {
                 ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_KAPPA4": "0"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
                 ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_WAVES": "4"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT)),
                 ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_COUNT4_WAVES": "8"}, False, (KIND_CLQ_BUILD, KIND_CLQ_COUNT))],
-    "triangle": [({}, True, ()), ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_MAX_CLASS": "1"}, False, (KIND_CLQ_BUILD,)),
+    "triangle": [({}, True, ()), ({"GPM_CLIQUE_TINY": "0"}, False, ()), ({"GPM_CLIQUE_TINY": "64"}, False, ()),
+                 ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_LISTS_MAX_CLASS": "1"}, False, (KIND_CLQ_BUILD,)),
                  ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_KAPPA4": "-1"}, False, (KIND_CLQ_BUILD,)),
                  ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_KAPPA4": "0"}, False, (KIND_CLQ_BUILD,)),
                  ({"GPM_CLIQUE_SMALL_MAX": "24"}, False, (KIND_CLQ_BUILD,))],
@@ -148,7 +152,7 @@ def test_large_goldens(spec, monkeypatch):
     dl, pl = util.build_labels(spec, n)
     for env, accounting, kinds in LARGE_PATHS.get(spec["pattern"], [({}, True, ())]):
         for k in ("GPM_CLIQUE_SMALL_MAX", "GPM_CLQ_LISTS_MAX_CLASS", "GPM_COUNT4_WAVES", "GPM_CYCLE4_HEAVY", "GPM_CLQ_KAPPA4",
-                  "GPM_CLQ_LISTS_WAVES"):
+                  "GPM_CLQ_LISTS_WAVES", "GPM_CLIQUE_TINY"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
