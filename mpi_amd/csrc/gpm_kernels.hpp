@@ -1927,8 +1927,9 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
     // The even list grows up from J[0], the odd list down from J[1023] (together they hold at most 1023
     // entries): entry t of one and entry t of the other then never lie on the same LDS bank, which they
     // would if the second list started half way (1024 bytes on).
-    const uint16_t *Jmine = my_res ? J + 1023 : J;
-    const int jdir = my_res ? -1 : 1;
+    // this lane block's first entry and the distance (in entries, signed) between two of its entries
+    const uint16_t *Jfirst = my_res ? J + 1023 - my_first : J + my_first;
+    const int jstep = my_res ? -my_step : my_step;
     // listing: lane l looks at four bits of each of the words (l & 7) + 8 k, k = 0..3: bits 4 (l >> 3) .. + 3.
     // A row is dense where its universe holds the highest-degree vertices (its last positions), and a lane
     // that held 16 neighbouring positions of that region would write its entries long after the others were
@@ -1958,14 +1959,21 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
                                : (uint32_t)__popc(bits);
         const uint32_t incl = wave_incl_scan_u32(c);
         const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, GPM_WAVE - 1);
-        uint32_t at0 = (incl - c) & 0xffffu, at1 = 1023u - ((incl - c) >> 16);  // next free entry, even / odd list
-        while (bits) {
-            const uint32_t b = (uint32_t)__builtin_ctz(bits);
-            bits &= bits - 1;
-            const bool odd = two && (b & 1u);
-            J[odd ? at1 : at0] = (uint16_t)((pos0 + ((b >> 2) << 8) + (b & 3u)) << lg);  // word (b >> 2) * 8 further on
-            at1 -= odd;
-            at0 += !odd;
+        // next free entry, even / odd list.  Bit b of `bits` is position pos0 + 256 (b >> 2) + (b & 3) (word
+        // (b >> 2) * 8 further on), an entry is that position's slot offset.  One loop per list keeps the
+        // parity out of the loop body.
+        uint16_t *at0 = J + ((incl - c) & 0xffffu), *at1 = J + 1023 - ((incl - c) >> 16);
+        const uint32_t entry0 = pos0 << lg;
+        uint32_t be = two ? bits & 0x5555u : bits, bo = two ? bits & 0xaaaau : 0u;
+        while (be) {
+            const uint32_t b = (uint32_t)__builtin_ctz(be);
+            be &= be - 1;
+            *at0++ = (uint16_t)(entry0 + ((((b & 12u) << 6) | (b & 3u)) << lg));
+        }
+        while (bo) {
+            const uint32_t b = (uint32_t)__builtin_ctz(bo);
+            bo &= bo - 1;
+            *at1-- = (uint16_t)(entry0 + ((((b & 12u) << 6) | (b & 3u)) << lg));
         }
         // the next row's words are requested once this row's have been used
         const int inext = i + step;
@@ -1980,17 +1988,18 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
         if (all && lane_ok) {
             uint32_t acc = 0;
             int t = my_first;
-            for (; t + 3 * my_step < my_len; t += 4 * my_step) {  // four independent row reads in flight
-                const u32x4 r0 = load4(lane_base + ((uint32_t)Jmine[jdir * t] << 2));
-                const u32x4 r1 = load4(lane_base + ((uint32_t)Jmine[jdir * (t + my_step)] << 2));
-                const u32x4 r2 = load4(lane_base + ((uint32_t)Jmine[jdir * (t + 2 * my_step)] << 2));
-                const u32x4 r3 = load4(lane_base + ((uint32_t)Jmine[jdir * (t + 3 * my_step)] << 2));
+            const uint16_t *jp = Jfirst;  // entry t of this block's list
+            for (; t + 3 * my_step < my_len; t += 4 * my_step, jp += 4 * jstep) {  // four independent row reads in flight
+                const u32x4 r0 = load4(lane_base + ((uint32_t)jp[0] << 2));
+                const u32x4 r1 = load4(lane_base + ((uint32_t)jp[jstep] << 2));
+                const u32x4 r2 = load4(lane_base + ((uint32_t)jp[2 * jstep] << 2));
+                const u32x4 r3 = load4(lane_base + ((uint32_t)jp[3 * jstep] << 2));
                 acc = and_popc_add4(C, r0, acc);
                 acc = and_popc_add4(C, r1, acc);
                 acc = and_popc_add4(C, r2, acc);
                 acc = and_popc_add4(C, r3, acc);
             }
-            for (; t < my_len; t += my_step) acc = and_popc_add4(C, load4(lane_base + ((uint32_t)Jmine[jdir * t] << 2)), acc);
+            for (; t < my_len; t += my_step, jp += jstep) acc = and_popc_add4(C, load4(lane_base + ((uint32_t)jp[0] << 2)), acc);
             total += acc;
         }
         wave_lds_sync();
