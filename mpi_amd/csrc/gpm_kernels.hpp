@@ -1713,10 +1713,12 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
         int64_t b;
         int n;
         range_of(0, b, n);
+        // a lane past the end of a list holds the root itself: it lies inside the bitmap's range and no
+        // universe holds its own root, so it fails the test like any other foreign vertex
 #pragma unroll
         for (int k = 0; k < CLQ_LIST_LOADS; ++k) {
             const int p = k * GPM_WAVE + lane;
-            cur[k] = p < n ? adj[b + p] : -1;
+            cur[k] = p < n ? adj[b + p] : u;
         }
         for (int r = 0; r < 64; ++r) {
             const int i = i_batch + r * step;
@@ -1727,21 +1729,19 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
 #pragma unroll
             for (int k = 0; k < CLQ_LIST_LOADS; ++k) {  // the next row's entries are in flight while this row is tested
                 const int p = k * GPM_WAVE + lane;
-                nxt[k] = p < nn ? adj[nb + p] : -1;
+                nxt[k] = p < nn ? adj[nb + p] : u;
             }
             if (K != 3) {
                 stage[lane] = 0;
                 stage[GPM_WAVE + lane] = 0;
                 wave_lds_sync();
             }
-            auto test = [&](int32_t w) {
-                if (w < 0) return;
-                const uint32_t c = (uint32_t)(w - base_id);
-                const uint32_t word = bm[c >> 5], bit = 1u << (c & 31);
-                if (!(word & bit)) return;
+            // the bitmap words of a batch of entries are all requested before the first is looked at
+            auto hit = [&](uint32_t c, uint32_t word) {
                 if (K == 3) {
                     tri += 1;
                 } else {
+                    const uint32_t bit = 1u << (c & 31);
                     const int j = (int)prefix[c >> 5] + __popc(word & (bit - 1));  // rank among the set bits = position in U
                     atomicOr(stage + (j >> 5), 1u << (j & 31));
                 }
@@ -1778,17 +1778,29 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
                     }
                 }
             }
+            if (n > 0) {
+                uint32_t c[CLQ_LIST_LOADS], word[CLQ_LIST_LOADS];
 #pragma unroll
-            for (int k = 0; k < CLQ_LIST_LOADS; ++k) test(cur[k]);
+                for (int k = 0; k < CLQ_LIST_LOADS; ++k) {
+                    c[k] = (uint32_t)(cur[k] - base_id);
+                    word[k] = bm[c[k] >> 5];
+                }
+#pragma unroll
+                for (int k = 0; k < CLQ_LIST_LOADS; ++k)
+                    if ((word[k] >> (c[k] & 31)) & 1u) hit(c[k], word[k]);
+            }
             for (int p0 = CLQ_LIST_LOADS * GPM_WAVE; p0 < n; p0 += 4 * GPM_WAVE) {  // the rest of a long list
-                int32_t w[4];
+                uint32_t c[4], word[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int p = p0 + k * GPM_WAVE + lane;
-                    w[k] = p < n ? adj[b + p] : -1;
+                    c[k] = (uint32_t)((p < n ? adj[b + p] : u) - base_id);
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) test(w[k]);
+                for (int k = 0; k < 4; ++k) word[k] = bm[c[k] >> 5];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((word[k] >> (c[k] & 31)) & 1u) hit(c[k], word[k]);
             }
             if (K != 3) {
                 wave_lds_sync();
