@@ -1020,6 +1020,19 @@ __device__ __forceinline__ u32x4 load4(const uint32_t *p) {
     return {v.x, v.y, v.z, v.w};
 }
 
+// popc(x) + acc in one instruction (the compiler otherwise counts into a fresh register and adds).
+__device__ __forceinline__ uint32_t popc_add(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t and_popc_add4(u32x4 c, u32x4 r, uint32_t acc) {
+    acc = popc_add(c.x & r.x, acc);
+    acc = popc_add(c.y & r.y, acc);
+    acc = popc_add(c.z & r.z, acc);
+    return popc_add(c.w & r.w, acc);
+}
+
 // Open-addressing hash of the universe U in LDS, used while the rows are built:
 // slot = (id & ~0x1fff) | (position + 1), 0 = empty.  The 19 tag bits reject
 // almost every foreign id without touching U.
@@ -1112,15 +1125,27 @@ __device__ __forceinline__ uint64_t clq_count(u32x4 C, const uint32_t *c_words, 
         const int G = GPM_WAVE >> q.lg;
         if (lane_ok) {
             const uint32_t *base = rows + 4 * sub;
-            int t = lane >> q.lg;
-            for (; t + 3 * G < cnt; t += 4 * G) {  // four independent row reads in flight
-                u32x4 r0 = load4(base + (size_t)ws.J[t] * q.Wp);
-                u32x4 r1 = load4(base + (size_t)ws.J[t + G] * q.Wp);
-                u32x4 r2 = load4(base + (size_t)ws.J[t + 2 * G] * q.Wp);
-                u32x4 r3 = load4(base + (size_t)ws.J[t + 3 * G] * q.Wp);
-                acc += popc4(and4(C, r0)) + popc4(and4(C, r1)) + popc4(and4(C, r2)) + popc4(and4(C, r3));
+            // row j starts j * Wp words in: a shift when Wp is a power of two (always, up to 256 vertices)
+            auto run = [&](auto row_of) {
+                int t = lane >> q.lg;
+                for (; t + 3 * G < cnt; t += 4 * G) {  // four independent row reads in flight
+                    const u32x4 r0 = load4(row_of(ws.J[t]));
+                    const u32x4 r1 = load4(row_of(ws.J[t + G]));
+                    const u32x4 r2 = load4(row_of(ws.J[t + 2 * G]));
+                    const u32x4 r3 = load4(row_of(ws.J[t + 3 * G]));
+                    acc = and_popc_add4(C, r0, acc);
+                    acc = and_popc_add4(C, r1, acc);
+                    acc = and_popc_add4(C, r2, acc);
+                    acc = and_popc_add4(C, r3, acc);
+                }
+                for (; t < cnt; t += G) acc = and_popc_add4(C, load4(row_of(ws.J[t])), acc);
+            };
+            if ((q.Wp & (q.Wp - 1)) == 0) {
+                const int sh = q.lg + 2;  // Wp = 4 L
+                run([&](uint32_t j) { return base + (j << sh); });
+            } else {
+                run([&](uint32_t j) { return base + (size_t)j * q.Wp; });
             }
-            for (; t < cnt; t += G) acc += popc4(and4(C, load4(base + (size_t)ws.J[t] * q.Wp)));
         }
         return acc;
     } else {
@@ -1820,19 +1845,6 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
         tri = wave_sum_u64(tri);
         if (lane == 0 && tri) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)tri);
     }
-}
-
-// popc(x) + acc in one instruction (the compiler otherwise counts into a fresh register and adds).
-__device__ __forceinline__ uint32_t popc_add(uint32_t x, uint32_t acc) {
-    uint32_t r;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
-    return r;
-}
-__device__ __forceinline__ uint32_t and_popc_add4(u32x4 c, u32x4 r, uint32_t acc) {
-    acc = popc_add(c.x & r.x, acc);
-    acc = popc_add(c.y & r.y, acc);
-    acc = popc_add(c.z & r.z, acc);
-    return popc_add(c.w & r.w, acc);
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave with data-parallel-primitive adds: four shifts inside
