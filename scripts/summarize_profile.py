@@ -21,7 +21,7 @@ os.makedirs(dst, exist_ok=True)
 SEARCH = ("k_clique", "k_clq_", "k_cycle4", "k_tail", "k_leaf_pair", "k_extend", "k_ranges", "k_filter_roots", "k_batch_end",
           "k_sum_slots")
 # kernel family (the names gpm_hip_kernel_name returns) -> prefixes of the kernels in it
-FAMILIES = {"k_tail": ("k_tail", "k_leaf_pair"), "k_extend": ("k_extend",), "k_clique": ("k_clique<",),
+FAMILIES = {"k_tail": ("k_tail", "k_leaf_pair"), "k_extend": ("k_extend",), "k_clique": ("k_clique<", "k_clique_tiny<"),
             "k_clq_build": ("k_clq_build",), "k_clq_count4": ("k_clq_count4",), "k_cycle4": ("k_cycle4_light", "k_cycle4_heavy")}
 
 
