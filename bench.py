@@ -440,6 +440,14 @@ def main():
                                  "(hub-matrix bits and LDS bitmaps instead of list passes); traffic_frac is the "
                                  "rate of the bytes HBM really moved"},
             "kernel_families_rank0": families,
+            "whole_search": None if not tj.get("valu_wave_instructions_per_search") or args.config != 3 or overridden else {
+                "note": "all kernels of one search, from the committed counter passes of these kernel sources: "
+                        "wave-level vector-ALU instructions against 256 CUs x 1 instruction per clock x 2.4 GHz, "
+                        "and HBM bytes moved against the nominal peak, both over this run's time per step",
+                "valu_wave_instructions": tj["valu_wave_instructions_per_search"],
+                "valu_issue_frac": tj["valu_wave_instructions_per_search"] / (256 * 2.4e9 * world) / sec_per_step,
+                "hbm_GB": tj.get("hbm_bytes_per_search", 0.0) / 1e9,
+                "hbm_frac": tj.get("hbm_bytes_per_search", 0.0) / 1e9 / sec_per_step / HBM_PEAK_GBS / world},
             "one_chunk_in_flight": None if alone is None else {
                 "note": "one extra search outside the timed region with launches not overlapping",
                 "ms_per_step": alone["ms_per_step"], "kernel": names[dom],

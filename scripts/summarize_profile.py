@@ -102,6 +102,8 @@ traffic = {"note": "read bytes = 2 x FETCH_SIZE KiB (gfx950 correction, calibrat
            "source": f"profiles/{tag}_pmc_summary.json", "kernels_fingerprint": fingerprint()}
 for fam, prefixes in FAMILIES.items():
     part = [v for k, v in summary.items() if k.startswith(prefixes)]
+    if not part:
+        continue
     calls = sum(v["calls"] for v in part)
     if not calls:
         continue
@@ -110,6 +112,13 @@ for fam, prefixes in FAMILIES.items():
     traffic[fam] = {"launches": calls, "hbm_bytes_total": hbm, "hbm_bytes_per_launch": hbm / calls,
                     "kernel_ms_total": ms, "kernel_avg_ms": ms / calls,
                     "hbm_GBps_while_running": hbm / 1e9 / (ms / 1e3) if ms else None}
+# wave-level vector-ALU instructions of all search kernels per search (the profiled command runs 1 warm-up
+# and 2 timed searches): the resource that bounds the clique search once HBM traffic is a third of the
+# merge model's bytes
+SEARCHES = 3
+traffic["searches_profiled"] = SEARCHES
+traffic["valu_wave_instructions_per_search"] = sum(v["SQ_INSTS_VALU"] for v in summary.values()) / SEARCHES
+traffic["hbm_bytes_per_search"] = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in summary.values()) / SEARCHES
 with open(os.path.join(dst, "hbm_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
     f.write("\n")
