@@ -95,7 +95,7 @@ enum {  // slots of the per-device counter block (unsigned long long each)
     CTR_TAIL_BYTES = 19,
     CTR_EMIT = 20,
     CTR_CYC_BYTES = 21,       // merge-model bytes of the 4-cycle kernels
-    CTR_OVER = 22,            // [22, 24): partial matches handed back by the two launches of the three-level kernel
+    CTR_OVER = 30,            // [30, 33): partial matches handed back by the launches (tiers) of the three-level kernel
     CTR_KIND_BYTES = 40,      // [40, 40 + GPM_KERNEL_KINDS): bytes summed out of the clique slots, per kind
     CTR_CLQ_CLASS0 = 24,  // [24, 29): roots per size class of the clique kernel
     CTR_COUNT = 48
@@ -1687,7 +1687,7 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
     if (a.count_only && ctx->use_tail && k == P - 3 && ctx->t3.enabled && !d.no_fuse3) {
         if (!d.over_rows) return fail(GPM_ESTATE, "hand-back lists of the three-level kernel were not allocated");
         int64_t *over1 = d.over_rows, *over2 = d.over_rows + d.cap_rows;
-        HIP_TRY(hipMemsetAsync(d.ctr + CTR_OVER, 0, 2 * sizeof(unsigned long long), s));
+        HIP_TRY(hipMemsetAsync(d.ctr + CTR_OVER, 0, 3 * sizeof(unsigned long long), s));
         // 8 lanes and sets of up to 64 per partial match; what does not fit goes to 16 lanes with sets of up
         // to 256, then to whole waves with sets of up to 1024; what still does not fit goes level by level
         const int64_t grp = ctx->fuse3_group;
@@ -1695,46 +1695,49 @@ static int expand(const SearchArgs &a, DevState &d, int k, int64_t nrows) {
         int rc = timed_begin(d, GPM_KIND_TAIL, nrows);
         if (rc) return rc;
         if (grp == 4)
-            k_tail3<4, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, over1,
+            k_tail3<4, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, nullptr, over1,
                                                  d.ctr + CTR_OVER, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_TAIL_BYTES);
         else if (grp == 8)
-            k_tail3<8, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, over1,
+            k_tail3<8, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, nullptr, over1,
                                                  d.ctr + CTR_OVER, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_TAIL_BYTES);
         else if (grp == 32)
-            k_tail3<32, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, over1,
+            k_tail3<32, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, nullptr, over1,
                                                   d.ctr + CTR_OVER, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_TAIL_BYTES);
         else
-            k_tail3<16, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, over1,
+            k_tail3<16, 64><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, nullptr, nrows, nullptr, over1,
                                                   d.ctr + CTR_OVER, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_TAIL_BYTES);
         HIP_TRY(hipGetLastError());
         if ((rc = timed_end(d))) return rc;
         uint64_t n_over = 0;
-        if ((rc = read_ctr(d, CTR_OVER, &n_over))) return rc;
-        if (n_over == 0) return GPM_OK;
         if (!ctx->fuse3_wave) {  // tests: straight to the level-by-level path
+            if ((rc = read_ctr(d, CTR_OVER, &n_over))) return rc;
+            if (n_over == 0) return GPM_OK;
             over2 = over1;
         } else {
+            // The wider tiers are enqueued behind the first without the host looking at the hand-back counts:
+            // each reads the number of its partial matches from the counter the tier before it left (a tier
+            // with nothing to do costs one empty launch), and the host reads one count, the last.  The grids
+            // are sized for the worst case the kernels' grid-stride loops make harmless: 2048 workgroups, more than fit the GPU at once.
+            const unsigned tier_blocks = 2048;
+            const unsigned long long *from = d.ctr + CTR_OVER;
             if (ctx->fuse3_mid) {  // sets of up to 256 with 16 lanes
-                blocks = (unsigned)std::min<uint64_t>((n_over * 16 + 255) / 256, 1 << 16);
-                if ((rc = timed_begin(d, GPM_KIND_TAIL, (int64_t)n_over))) return rc;
-                k_tail3<16, 256><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, over1, (int64_t)n_over,
-                                                       over2, d.ctr + CTR_OVER + 1, d.ctr + CTR_TAIL_MATCHES,
-                                                       d.ctr + CTR_TAIL_BYTES);
+                if ((rc = timed_begin(d, GPM_KIND_TAIL, 0))) return rc;
+                k_tail3<16, 256><<<tier_blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, over1, 0, from, over2,
+                                                            d.ctr + CTR_OVER + 1, d.ctr + CTR_TAIL_MATCHES,
+                                                            d.ctr + CTR_TAIL_BYTES);
                 HIP_TRY(hipGetLastError());
                 if ((rc = timed_end(d))) return rc;
-                if ((rc = read_ctr(d, CTR_OVER + 1, &n_over))) return rc;
-                if (n_over == 0) return GPM_OK;
                 std::swap(over1, over2);  // over1: what is left; over2 free again
-                HIP_TRY(hipMemsetAsync(d.ctr + CTR_OVER + 1, 0, sizeof(unsigned long long), s));
+                from = d.ctr + CTR_OVER + 1;
             }
-            blocks = (unsigned)std::min<uint64_t>((n_over * 64 + 255) / 256, 1 << 16);
-            if ((rc = timed_begin(d, GPM_KIND_TAIL, (int64_t)n_over))) return rc;
-            k_tail3<64, 1024><<<blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, over1, (int64_t)n_over,
-                                                    over2, d.ctr + CTR_OVER + 1, d.ctr + CTR_TAIL_MATCHES,
-                                                    d.ctr + CTR_TAIL_BYTES);
+            // whole waves, sets of up to 1024; its own hand-back count goes to a third counter
+            if ((rc = timed_begin(d, GPM_KIND_TAIL, 0))) return rc;
+            k_tail3<64, 1024><<<tier_blocks, 256, 0, s>>>(d.gv, ctx->pv, ctx->ti, ctx->t3, rows, over1, 0, from, over2,
+                                                         d.ctr + CTR_OVER + 2, d.ctr + CTR_TAIL_MATCHES,
+                                                         d.ctr + CTR_TAIL_BYTES);
             HIP_TRY(hipGetLastError());
             if ((rc = timed_end(d))) return rc;
-            if ((rc = read_ctr(d, CTR_OVER + 1, &n_over))) return rc;
+            if ((rc = read_ctr(d, CTR_OVER + 2, &n_over))) return rc;
             if (n_over == 0) return GPM_OK;
         }
         // the partial matches whose sets did not fit a lane group: compact them to the front of this

@@ -533,11 +533,14 @@ __device__ __forceinline__ bool t3_level_ok(const GraphView &g, const LevelPlan 
     return vertex_ok(g, lv, c);
 }
 
+// `nrows_dev` (optional): the number of entries of `sel` sits in device memory (the hand-back count of the
+// launch before), so that a tier can be enqueued without the host reading that count first.
 template <int G, int CAP>
 __global__ __launch_bounds__(256) void k_tail3(GraphView g, PlanView pl, TailInfo ti, Tail3Info t3, const int32_t *rows,
-                                               const int64_t *sel, int64_t nrows, int64_t *over,
-                                               unsigned long long *n_over, unsigned long long *n_matches,
+                                               const int64_t *sel, int64_t nrows, const unsigned long long *nrows_dev,
+                                               int64_t *over, unsigned long long *n_over, unsigned long long *n_matches,
                                                unsigned long long *alg_bytes) {
+    if (nrows_dev) nrows = (int64_t)*nrows_dev;
     __shared__ int32_t s_z[256 / G][CAP], s_b[256 / G][CAP];
     const int lane = lane_id(), sub = lane & (G - 1), shift = lane & ~(G - 1), grp = threadIdx.x / G;
     const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1);
