@@ -609,7 +609,29 @@ __global__ __launch_bounds__(256) void k_tail3(GraphView g, PlanView pl, TailInf
         for (int zi = sub; zi < nz; zi += G) {
             const int32_t z = zs[zi];
             uint32_t sc = 0;
-            for (int bi = 0; bi < nb; ++bi) {
+            int bi = 0;
+            if (z >= g.hub_base) {
+                // every member of B above the hub base is one bit of z's row of the hub matrix: four
+                // independent probes in flight (the loop is bound by their latency, not by instructions)
+                const uint32_t *hrow = g.hub + (size_t)(z - g.hub_base) * (size_t)g.hub_wpr;
+                for (; bi + 4 <= nb; bi += 4) {
+                    int32_t b[4];
+                    uint32_t w[4];
+                    bool hub[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        b[k] = bs[bi + k];
+                        hub[k] = b[k] >= g.hub_base;
+                        w[k] = hub[k] ? hrow[(uint32_t)(b[k] - g.hub_base) >> 5] : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (hub[k]) sc += b[k] != z && ((w[k] >> ((uint32_t)(b[k] - g.hub_base) & 31)) & 1u);
+                        else sc += b[k] != z && in_list(g, 0, PART_FULL, z, b[k]);
+                    }
+                }
+            }
+            for (; bi < nb; ++bi) {
                 const int32_t b = bs[bi];
                 sc += b != z && in_list(g, 0, PART_FULL, z, b);
             }
