@@ -1,5 +1,5 @@
 #!/bin/bash
-# Knob sweep on the round-2 kernels after the hybrid row builder: one bench line per setting.
+# Knob sweep on the kernels with the per-row list/gather row builder: one bench line per setting.
 out=gpurun_out/sweep_r2b
 mkdir -p $out
 run() {
