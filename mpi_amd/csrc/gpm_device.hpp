@@ -24,6 +24,15 @@ struct GraphView {
     int32_t hub_base;       // n when there is no hub matrix
     int32_t hub_wpr;        // 32-bit words per row
     const uint32_t *hub;
+    // Summary of the hub matrix, one bit per 32-bit word of it (set iff the word is not zero), hub_cwpr
+    // words per row: 1/32 of the matrix, small enough to stay in the caches.  Nine words in ten of the
+    // matrix are zero, so a kernel that tests scattered pairs asks the summary first and fetches a line of
+    // the matrix itself only for the words that hold something.  nullptr: no summary.
+    // Columns from hub_dense on (the highest-degree vertices, where most words hold a bit) are read from the
+    // matrix directly; 0 without a summary.
+    int32_t hub_cwpr;
+    int32_t hub_dense;
+    const uint32_t *hubc;
     // labcnt[v * nlab + l] = neighbours of v that carry label l (symmetric
     // labelled graphs only, else nullptr): lets a leaf level be counted
     // without walking the list.

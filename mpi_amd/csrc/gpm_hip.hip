@@ -142,7 +142,7 @@ struct DevState {
     int32_t *adj[2] = {nullptr, nullptr};
     int32_t *perm = nullptr;
     uint8_t *label = nullptr;
-    uint32_t *hub = nullptr;
+    uint32_t *hub = nullptr, *hubc = nullptr;  // hub matrix and its summary (one bit per word)
     uint32_t *labcnt = nullptr, *labseg = nullptr;
     int32_t *adjL = nullptr;
     GraphView gv{};
@@ -396,6 +396,7 @@ static void free_graph(DevState &d) {
     dev_free(d.perm);
     dev_free(d.label);
     dev_free(d.hub);
+    dev_free(d.hubc);
     dev_free(d.labcnt);
     dev_free(d.labseg);
     dev_free(d.adjL);
@@ -412,7 +413,7 @@ static void free_graph(DevState &d) {
     d.labcnt = nullptr;
     d.perm = nullptr;
     d.label = nullptr;
-    d.hub = nullptr;
+    d.hub = d.hubc = nullptr;
 }
 
 static void free_buffers(DevState &d) {
@@ -736,6 +737,9 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
     d.gv.hub_base = n;
     d.gv.hub_wpr = 0;
     d.gv.hub = nullptr;
+    d.gv.hub_cwpr = 0;
+    d.gv.hub_dense = 0;
+    d.gv.hubc = nullptr;
     if (hub_rows > 0 && n > 0) {
         const size_t bytes = (size_t)hub_rows * (size_t)(hub_rows / 32) * sizeof(uint32_t);
         // Every kernel runs without the matrix (membership by binary search, rows from hashed list walks), so a
@@ -752,7 +756,19 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
             d.gv.hub_base = (int32_t)std::max<int64_t>(0, (int64_t)n - hub_rows);
             d.gv.hub_wpr = (int32_t)(hub_rows / 32);
             d.gv.hub = d.hub;
-            k_hub_fill<<<(unsigned)(n - d.gv.hub_base), 256, 0, s>>>(d.gv, d.hub);
+            // the summary (1/32 of the matrix) is optional as well: GPM_HUB_SUMMARY=0 or no memory for it
+            d.gv.hub_cwpr = (d.gv.hub_wpr + 31) / 32;
+            const size_t sum_bytes = (size_t)hub_rows * (size_t)d.gv.hub_cwpr * sizeof(uint32_t);
+            if (env_i64("GPM_HUB_SUMMARY", 1) != 0 && hipMalloc(&d.hubc, sum_bytes) == hipSuccess) {
+                HIP_TRY(hipMemsetAsync(d.hubc, 0, sum_bytes, s));
+                d.gv.hubc = d.hubc;
+                // the last GPM_HUB_DENSE columns (highest degrees) are probed without the summary
+                d.gv.hub_dense = (int32_t)std::max<int64_t>(0, hub_rows - std::max<int64_t>(0, env_i64("GPM_HUB_DENSE", 8192)));
+            } else {
+                (void)hipGetLastError();
+                d.hubc = nullptr;
+            }
+            k_hub_fill<<<(unsigned)(n - d.gv.hub_base), 256, 0, s>>>(d.gv, d.hub, d.hubc);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(s));
         }

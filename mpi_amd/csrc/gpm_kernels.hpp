@@ -929,15 +929,17 @@ __global__ void k_label_counts(GraphView g, uint32_t *labcnt) {
 // ---------------------------------------------------------------------------
 
 // One workgroup per hub vertex: set the bits of its arcs to other hubs.
-__global__ void k_hub_fill(GraphView g, uint32_t *bits) {
+__global__ void k_hub_fill(GraphView g, uint32_t *bits, uint32_t *summary) {
     const int32_t v = g.hub_base + blockIdx.x;
     if (v >= g.n) return;
     const int64_t e = g.off[0][v + 1];
     int64_t b = lower_bound_g(g.adj[0], g.off[0][v], e, g.hub_base);
     uint32_t *row = bits + (size_t)blockIdx.x * (size_t)g.hub_wpr;
+    uint32_t *srow = summary ? summary + (size_t)blockIdx.x * (size_t)g.hub_cwpr : nullptr;
     for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
         uint32_t c = (uint32_t)(g.adj[0][i] - g.hub_base);
         atomicOr(row + (c >> 5), 1u << (c & 31));
+        if (srow) atomicOr(srow + (c >> 10), 1u << ((c >> 5) & 31));  // word c >> 5 of the row holds a bit
     }
 }
 
@@ -1265,23 +1267,30 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
             if (v >= g.hub_base &&
                 (probe_bias == 0 || (int64_t)Dp[i] * 16 >= (int64_t)probe_bias * (int64_t)(d - 1 - i))) {
                 const uint32_t *hrow = g.hub + (size_t)(v - g.hub_base) * (size_t)g.hub_wpr;
-                // 256 positions per trip: four independent gathers in flight (Wp*32 is a multiple of 128)
+                const uint32_t *crow = g.hubc ? g.hubc + (size_t)(v - g.hub_base) * (size_t)g.hub_cwpr : nullptr;
+                // 256 positions per trip: four independent gathers in flight (Wp*32 is a multiple of 128);
+                // the summary of the row is asked first, the matrix only for words that hold a bit
                 for (int j0 = 0; j0 < Wp * 32; j0 += CLQ_GATHERS * GPM_WAVE) {
                     uint32_t word[CLQ_GATHERS];
                     uint32_t sh[CLQ_GATHERS];
                     bool live[CLQ_GATHERS];
+                    uint32_t col[CLQ_GATHERS], sum[CLQ_GATHERS];
 #pragma unroll
                     for (int k = 0; k < CLQ_GATHERS; ++k) {
                         const int j = j0 + k * GPM_WAVE + lane;
                         live[k] = j > i && j < d;
+                        col[k] = live[k] ? (uint32_t)(U[j] - g.hub_base) : 0u;
+                        sum[k] = 0;
                         word[k] = 0;
-                        sh[k] = 0;
+                        sh[k] = col[k] & 31;
                         if (live[k]) {
-                            uint32_t c = (uint32_t)(U[j] - g.hub_base);
-                            word[k] = hrow[c >> 5];
-                            sh[k] = c & 31;
+                            if (col[k] >= (uint32_t)g.hub_dense) word[k] = hrow[col[k] >> 5];
+                            else sum[k] = crow[col[k] >> 10];
                         }
                     }
+#pragma unroll
+                    for (int k = 0; k < CLQ_GATHERS; ++k)
+                        if ((sum[k] >> ((col[k] >> 5) & 31)) & 1u) word[k] = hrow[col[k] >> 5];
 #pragma unroll
                     for (int k = 0; k < CLQ_GATHERS; ++k) {
                         const int jb = j0 + k * GPM_WAVE;
@@ -1397,6 +1406,7 @@ __global__ __launch_bounds__(256) void k_clique_tiny(GraphView g, const int32_t 
     if (G <= 16) dmax = max(dmax, __shfl_xor(dmax, 16, GPM_WAVE));
     const bool my_hub = my_v >= g.hub_base;  // then every vertex above it is a hub as well
     const uint32_t *hrow = my_hub ? g.hub + (size_t)(my_v - g.hub_base) * (size_t)g.hub_wpr : nullptr;
+    const uint32_t *crow = my_hub && g.hubc ? g.hubc + (size_t)(my_v - g.hub_base) * (size_t)g.hub_cwpr : nullptr;
     const uint32_t my_dp = (uint32_t)(my_e - my_b);
     const uint64_t per_arc = 12ull + 4ull * ((uint64_t)d + my_dp);
     uint64_t bytes = 0;
@@ -1404,7 +1414,7 @@ __global__ __launch_bounds__(256) void k_clique_tiny(GraphView g, const int32_t 
     row_t row = 0;
     for (int j0 = 1; j0 < dmax; j0 += 4) {  // four probes in flight per lane
         int32_t w[4];
-        uint32_t word[4], dpw[4];
+        uint32_t word[4], sum[4], dpw[4];
         bool live[4], in[4];
         int64_t sb[4], se[4];  // binary searches of the lanes whose vertex is not a hub, advanced together
 #pragma unroll
@@ -1414,10 +1424,20 @@ __global__ __launch_bounds__(256) void k_clique_tiny(GraphView g, const int32_t 
             dpw[k] = STATS ? (uint32_t)__shfl((int)my_dp, base + (j & (G - 1)), GPM_WAVE) : 0u;
             live[k] = j < G && j > sub && j < d;
             word[k] = 0;
-            if (live[k] && my_hub) word[k] = hrow[(uint32_t)(w[k] - g.hub_base) >> 5];
+            sum[k] = 0;
+            if (live[k] && my_hub) {  // dense columns straight from the matrix, the others ask the summary first
+                const uint32_t c = (uint32_t)(w[k] - g.hub_base);
+                if (c >= (uint32_t)g.hub_dense) word[k] = hrow[c >> 5];
+                else sum[k] = crow[c >> 10];
+            }
             const bool srch = live[k] && !my_hub;
             sb[k] = srch ? my_b : 0;
             se[k] = srch ? my_e : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // the matrix itself only for the words that hold a bit
+            const uint32_t c = (uint32_t)(w[k] - g.hub_base);
+            if ((sum[k] >> ((c >> 5) & 31)) & 1u) word[k] = hrow[c >> 5];
         }
         while ((sb[0] < se[0]) | (sb[1] < se[1]) | (sb[2] < se[2]) | (sb[3] < se[3])) {
             int32_t x[4];
