@@ -193,6 +193,8 @@ struct DevState {
     int64_t cyc_stride = 0;
     int cyc_blocks = 0;
     int cyc_batch = 1;     // heavy roots per launch
+    int32_t *cyc_single = nullptr;  // copy of gpm_ctx::cyc_single_v1
+    uint64_t cyc_single_ver = 0;
     LeafTerm *ls_terms = nullptr;  // inclusion-exclusion terms of the leaf-suffix kernel
     unsigned long long *cyc_queue = nullptr;
     std::vector<EventPair> events;
@@ -238,9 +240,16 @@ struct gpm_ctx {
     int clique_small_max = 256;  // GPM_CLIQUE_SMALL_MAX
     int clique_tiny = 32;        // GPM_CLIQUE_TINY: largest universe of the lane-group kernel (0, 16, 32 or 64)
     int64_t cyc_heavy_block = 2048, cyc_span = (int64_t)1 << 18;
-    int64_t cyc_heavy_thr = 0;             // two-paths from which a root is cut into spans (k_cycle4_heavy)
+    CycRule cyc_rule{};                     // which 4-cycle kernel takes a root (thresholds, counters per LDS range)
+    int cyc_range_tiles = CYC_RANGE_TILES;  // tiles of 64 arcs per wave of such a task
     std::vector<int64_t> cyc_heavy_roots;  // root indices at or above the threshold, ascending
     std::vector<int64_t> cyc_heavy_paths;  // their two-path counts
+    std::vector<int64_t> cyc_heavy_arcs;   // their arcs to lower vertices
+    // heavy roots that count in LDS ranges and whose arcs fit one task: root indices (ascending) and
+    // vertices; every device keeps a copy of the vertex list (cyc_single), refreshed when the version moves
+    std::vector<int64_t> cyc_single_roots;
+    std::vector<int32_t> cyc_single_v1;
+    uint64_t cyc_single_ver = 0;
     int64_t chunk_roots = 1 << 20;  // upper bound of a chunk's size
     int64_t chunk_hint = 0;         // how many chunks to aim for (0 = 32 per GPU of the context)
     std::vector<Chunk> chunks;
@@ -407,6 +416,9 @@ static void free_graph(DevState &d) {
     d.cyc_wp = nullptr;
     dev_free(d.cyc_dense);
     dev_free(d.cyc_queue);
+    dev_free(d.cyc_single);
+    d.cyc_single = nullptr;
+    d.cyc_single_ver = 0;
     d.cyc_cost = nullptr;
     d.cyc_dense = nullptr;
     d.cyc_queue = nullptr;
@@ -539,7 +551,7 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->use_tail = env_i64("GPM_NO_TAIL", 0) == 0;
     ctx->use_clique = env_i64("GPM_NO_CLIQUE", 0) == 0;
     ctx->use_cycle4 = env_i64("GPM_NO_CYCLE4", 0) == 0;
-    ctx->cyc_heavy_thr = std::max<int64_t>(1, env_i64("GPM_CYCLE4_HEAVY", (int64_t)1 << 16));
+    ctx->cyc_rule.heavy_from = std::max<int64_t>(1, env_i64("GPM_CYCLE4_HEAVY", (int64_t)1 << 16));
     ctx->accounting = env_i64("GPM_ACCOUNTING", 1) != 0;
     {
         const char *gm = getenv("GPM_GATHER");
@@ -556,6 +568,13 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
         const int64_t t = env_i64("GPM_CLIQUE_TINY", 32);
         ctx->clique_tiny = t >= 64 ? 64 : t >= 32 ? 32 : t >= 16 ? 16 : 0;
     }
+    // GPM_CYC_RANGES=0: no root counts in LDS ranges (heavy roots are cut into spans on global counter arrays)
+    ctx->cyc_rule.S = env_i64("GPM_CYC_RANGES", 1) == 0
+                          ? 0
+                          : (int)std::min<int64_t>(CYC_RANGE_MAX_IDS, std::max<int64_t>(256, env_i64("GPM_CYC_RANGE_IDS", 16384))) / 4 * 4;
+    ctx->cyc_rule.ranged_from = std::max<int64_t>(1, env_i64("GPM_CYC_RANGES_FROM", (int64_t)1 << 12));
+    ctx->cyc_rule.per_range = (int32_t)std::max<int64_t>(0, env_i64("GPM_CYC_RANGE_WORK", 64));
+    ctx->cyc_range_tiles = (int)std::min<int64_t>(CYC_RANGE_TILES, std::max<int64_t>(1, env_i64("GPM_CYC_RANGE_TILES", CYC_RANGE_TILES)));
     ctx->cyc_heavy_block = std::max<int64_t>(256, env_i64("GPM_CYC_HEAVY_BLOCK", 2048)) / 256 * 256;
     ctx->cyc_span = std::max<int64_t>(1, env_i64("GPM_CYC_SPAN", (int64_t)1 << 18) / ctx->cyc_heavy_block) * ctx->cyc_heavy_block;
     for (auto &d : ctx->devs) {
@@ -2125,6 +2144,8 @@ static int ensure_cycle4(gpm_ctx *ctx, DevState &d) {
     }
     HIP_TRY(hipFuncSetAttribute((const void *)k_cycle4_heavy, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)CYC_HEAVY_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_cycle4_ranges, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)CYC_RANGE_LDS_BYTES(CYC_RANGE_MAX_IDS)));
     if (n > 0) k_cycle4_cost<<<grid_for(n), 256, 0, s>>>(d.gv, d.cyc_wp, n, d.cyc_cost);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -2175,10 +2196,31 @@ static int prepare_chunks(gpm_ctx *ctx) {
     if (cyc)
         for (int64_t i = 0; i < nroots; ++i) {
             const int64_t paths = hpref[(size_t)i] - (i ? hpref[(size_t)i - 1] : 0) - 1;
-            if (paths >= ctx->cyc_heavy_thr) {
+            if (cyc_is_heavy(ctx->cyc_rule, paths, (int32_t)(ctx->info.n - 1 - (lo + i)))) {
                 ctx->cyc_heavy_roots.push_back(lo + i);
                 ctx->cyc_heavy_paths.push_back(paths);
             }
+        }
+    ctx->cyc_heavy_arcs.assign(ctx->cyc_heavy_roots.size(), 0);
+    if (!ctx->cyc_heavy_roots.empty()) {
+        const size_t nh = ctx->cyc_heavy_roots.size();
+        Scratch idx_buf, arcs_buf;
+        HIP_TRY(idx_buf.alloc(nh * sizeof(int64_t)));
+        HIP_TRY(arcs_buf.alloc(nh * sizeof(int64_t)));
+        HIP_TRY(hipMemcpyAsync(idx_buf.p, ctx->cyc_heavy_roots.data(), nh * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        k_cycle4_root_arcs<<<grid_for((int64_t)nh), 256, 0, s>>>(d.gv, idx_buf.as<int64_t>(), (int64_t)nh, arcs_buf.as<int64_t>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ctx->cyc_heavy_arcs.data(), arcs_buf.p, nh * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    ctx->cyc_single_roots.clear();
+    ctx->cyc_single_v1.clear();
+    ctx->cyc_single_ver++;
+    for (size_t h = 0; h < ctx->cyc_heavy_roots.size(); ++h)
+        if (cyc_is_ranged(ctx->cyc_rule, ctx->cyc_heavy_paths[h], (int32_t)(ctx->info.n - 1 - ctx->cyc_heavy_roots[h])) &&
+            ctx->cyc_heavy_arcs[h] <= (int64_t)CYC_HEAVY_WAVES * GPM_WAVE * ctx->cyc_range_tiles) {
+            ctx->cyc_single_roots.push_back(ctx->cyc_heavy_roots[h]);
+            ctx->cyc_single_v1.push_back((int32_t)(ctx->info.n - 1 - ctx->cyc_heavy_roots[h]));
         }
     int64_t want = ctx->chunk_hint > 0 ? ctx->chunk_hint : 32 * (int64_t)ctx->devs.size();
     // the two-path counts are exact costs and every chunk is one persistent launch: few, large chunks
@@ -2258,6 +2300,14 @@ static int device_search(const SearchArgs &a, DevState &d) {
     const bool cyc = a.count_only && ctx->cycle4 && ctx->use_cycle4 && !a.fixed_memory;
     if (cyc) {
         if ((rc = ensure_cycle4(ctx, d))) return rc;
+        if (d.cyc_single_ver != ctx->cyc_single_ver) {
+            dev_free(d.cyc_single);
+            d.cyc_single = nullptr;
+            const size_t bytes = ctx->cyc_single_v1.size() * sizeof(int32_t);
+            HIP_TRY(hipMalloc(&d.cyc_single, bytes ? bytes : 8));
+            if (bytes) HIP_TRY(hipMemcpyAsync(d.cyc_single, ctx->cyc_single_v1.data(), bytes, hipMemcpyHostToDevice, s));
+            d.cyc_single_ver = ctx->cyc_single_ver;
+        }
         HIP_TRY(hipMemsetAsync(d.cyc_queue, 0, 1024 * sizeof(unsigned long long), s));
         HIP_TRY(hipStreamSynchronize(s));
     }
@@ -2296,41 +2346,75 @@ static int device_search(const SearchArgs &a, DevState &d) {
             d.rows_in[0] += (uint64_t)(hi - lo);
             if ((rc = timed_begin(d, GPM_KIND_CYCLE4, hi - lo, ls))) return rc;
             k_cycle4_light<<<(unsigned)d.cyc_blocks, 256, 0, ls>>>(d.gv, d.cyc_wp, lo, hi, d.cyc_cost,
-                                                                  ctx->cyc_heavy_thr, d.cyc_queue + seq % 1024,
+                                                                  ctx->cyc_rule, d.cyc_queue + seq % 1024,
                                                                   d.cyc_dense, d.cyc_stride, d.ctr + CTR_TAIL_MATCHES,
                                                                   d.ctr + CTR_CYC_BYTES);
             HIP_TRY(hipGetLastError());
             if ((rc = timed_end(d, ls))) return rc;
             seq++;
             const auto &hv = ctx->cyc_heavy_roots;
-            // heavy roots of the chunk, CYC_BATCH per launch; the light launches keep a stream (and with it
-            // a hardware queue) of their own, so the batches alternate between the other three
+            // heavy roots of the chunk, up to CYC_BATCH per launch; the light launches keep a stream (and
+            // with it a hardware queue) of their own, so the batches alternate between the other three.
+            // Roots with enough two-paths per range of ids (cyc_is_ranged) count in LDS, one workgroup per
+            // block of arcs, S counters at a time; the others are cut into spans of two-paths.
             const int64_t hblock = ctx->cyc_heavy_block, span = ctx->cyc_span;
-            size_t h = (size_t)(std::lower_bound(hv.begin(), hv.end(), lo) - hv.begin());
-            while (h < hv.size() && hv[h] < hi) {
-                CycBatch b{};
-                int64_t max_v1 = 0;
-                while (b.n < d.cyc_batch && h < hv.size() && hv[h] < hi) {
-                    b.v1[b.n] = (int32_t)(ctx->info.n - 1 - hv[h]);
-                    max_v1 = std::max<int64_t>(max_v1, b.v1[b.n]);
-                    b.wg0[b.n + 1] = b.wg0[b.n] + (int32_t)((ctx->cyc_heavy_paths[h] + span - 1) / span);
-                    b.n++;
-                    h++;
+            const int S = ctx->cyc_rule.S;
+            const size_t h_lo = (size_t)(std::lower_bound(hv.begin(), hv.end(), lo) - hv.begin());
+            if (S) {  // ranged roots of one task each: one launch for all of them
+                const auto &sr = ctx->cyc_single_roots;
+                const size_t i0 = (size_t)(std::lower_bound(sr.begin(), sr.end(), lo) - sr.begin());
+                const size_t i1 = (size_t)(std::lower_bound(sr.begin(), sr.end(), hi) - sr.begin());
+                if (i1 > i0) {
+                    hipStream_t hs = d.slots[(int)(cyc_heavy_seq++ % CYC_HEAVY_GROUPS) + 1].stream;
+                    if ((rc = timed_begin(d, GPM_KIND_CYCLE4, (int64_t)(i1 - i0), hs))) return rc;
+                    k_cycle4_ranges<<<(unsigned)(i1 - i0), CYC_HEAVY_WAVES * GPM_WAVE, CYC_RANGE_LDS_BYTES(S), hs>>>(
+                        d.gv, d.cyc_wp, CycBatch{}, d.cyc_single + i0, S, ctx->cyc_range_tiles, nullptr, 0,
+                        d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_CYC_BYTES);
+                    HIP_TRY(hipGetLastError());
+                    if ((rc = timed_end(d, hs))) return rc;
                 }
-                const int group = (int)(cyc_heavy_seq++ % CYC_HEAVY_GROUPS);
-                hipStream_t hs = d.slots[group + 1].stream;
-                uint32_t *dense = d.cyc_dense + ((size_t)d.cyc_blocks + (size_t)group * d.cyc_batch) * (size_t)d.cyc_stride;
-                if ((rc = timed_begin(d, GPM_KIND_CYCLE4, b.n, hs))) return rc;
-                k_cycle4_heavy<<<(unsigned)b.wg0[b.n], CYC_HEAVY_WAVES * GPM_WAVE, CYC_HEAVY_LDS_BYTES, hs>>>(
-                    d.gv, d.cyc_wp, b, dense, d.cyc_stride, span, hblock, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_CYC_BYTES);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemsetAsync(dense, 0, ((size_t)(b.n - 1) * (size_t)d.cyc_stride + (size_t)max_v1) * sizeof(uint32_t), hs));
-                if ((rc = timed_end(d, hs))) return rc;
-                progress_tick(d.dev, d.chunks, ctx->chunks.size(), 0, (int64_t)h);
-                if (d.events_used > 4096) {
-                    for (auto &x : d.slots) HIP_TRY(hipStreamSynchronize(x.stream));
-                    HIP_TRY(hipStreamSynchronize(s));
-                    if ((rc = collect_times(d, ctx->trace))) return rc;
+            }
+            for (int ranged = S ? 1 : 0; ranged >= 0; --ranged) {
+                size_t h = h_lo;
+                while (h < hv.size() && hv[h] < hi) {
+                    CycBatch b{};
+                    int64_t max_v1 = 0;
+                    bool shared_arrays = !ranged;  // a ranged launch needs the arrays only for roots of several arc blocks
+                    for (; b.n < d.cyc_batch && h < hv.size() && hv[h] < hi; ++h) {
+                        const int64_t paths = ctx->cyc_heavy_paths[h];
+                        const int32_t v1 = (int32_t)(ctx->info.n - 1 - hv[h]);
+                        if (cyc_is_ranged(ctx->cyc_rule, paths, v1) != (bool)ranged) continue;
+                        const int64_t block_arcs = (int64_t)CYC_HEAVY_WAVES * GPM_WAVE * ctx->cyc_range_tiles;
+                        const int64_t tasks = ranged ? (ctx->cyc_heavy_arcs[h] + block_arcs - 1) / block_arcs : (paths + span - 1) / span;
+                        if (ranged && tasks == 1) continue;  // launched above
+                        if (b.n && (int64_t)b.wg0[b.n] + tasks > (int64_t)1 << 20) break;  // next launch
+                        b.v1[b.n] = v1;
+                        shared_arrays |= tasks > 1;
+                        max_v1 = std::max<int64_t>(max_v1, v1);
+                        b.wg0[b.n + 1] = b.wg0[b.n] + (int32_t)tasks;
+                        b.n++;
+                    }
+                    if (!b.n) break;
+                    const int group = (int)(cyc_heavy_seq++ % CYC_HEAVY_GROUPS);
+                    hipStream_t hs = d.slots[group + 1].stream;
+                    uint32_t *dense = d.cyc_dense + ((size_t)d.cyc_blocks + (size_t)group * d.cyc_batch) * (size_t)d.cyc_stride;
+                    if ((rc = timed_begin(d, GPM_KIND_CYCLE4, b.n, hs))) return rc;
+                    if (ranged)
+                        k_cycle4_ranges<<<(unsigned)b.wg0[b.n], CYC_HEAVY_WAVES * GPM_WAVE, CYC_RANGE_LDS_BYTES(S), hs>>>(
+                            d.gv, d.cyc_wp, b, nullptr, S, ctx->cyc_range_tiles, dense, d.cyc_stride, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_CYC_BYTES);
+                    else
+                        k_cycle4_heavy<<<(unsigned)b.wg0[b.n], CYC_HEAVY_WAVES * GPM_WAVE, CYC_HEAVY_LDS_BYTES, hs>>>(
+                            d.gv, d.cyc_wp, b, dense, d.cyc_stride, span, hblock, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_CYC_BYTES);
+                    HIP_TRY(hipGetLastError());
+                    if (shared_arrays)
+                        HIP_TRY(hipMemsetAsync(dense, 0, ((size_t)(b.n - 1) * (size_t)d.cyc_stride + (size_t)max_v1) * sizeof(uint32_t), hs));
+                    if ((rc = timed_end(d, hs))) return rc;
+                    progress_tick(d.dev, d.chunks, ctx->chunks.size(), 0, (int64_t)h);
+                    if (d.events_used > 4096) {
+                        for (auto &x : d.slots) HIP_TRY(hipStreamSynchronize(x.stream));
+                        HIP_TRY(hipStreamSynchronize(s));
+                        if ((rc = collect_times(d, ctx->trace))) return rc;
+                    }
                 }
             }
             continue;

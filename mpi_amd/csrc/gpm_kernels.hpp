@@ -2133,6 +2133,14 @@ __global__ void k_cycle4_cost(GraphView g, const int64_t *wp, int64_t nroots, in
     cost[i] = wp[g.mid[0][v1]] - wp[g.off[0][v1]] + 1;
 }
 
+// arcs[i] = arcs of root index idx[i] (vertex n-1-idx[i]) that lead below it.
+__global__ void k_cycle4_root_arcs(GraphView g, const int64_t *idx, int64_t count, int64_t *arcs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int32_t v1 = (int32_t)(g.n - 1 - idx[i]);
+    arcs[i] = g.mid[0][v1] - g.off[0][v1];
+}
+
 // One wave's pass over blocks blk0, blk0 + bstep, ... of the two-paths of root
 // v1.  RESET = false: count, returns the sum of the old counter values;
 // RESET = true: store zeros.  s_pre / s_beg are this wave's 64-entry LDS arrays.
@@ -2234,13 +2242,29 @@ __device__ __forceinline__ uint64_t cyc_wave_pass(const GraphView &g, const int6
     return acc;
 }
 
+// Which kernel counts a root of `paths` two-paths.  Counters in LDS (k_cycle4_ranges) cost a fixed amount per
+// range of S ids below the root, whatever the root's work, so a root takes them when it has at least
+// `per_range` two-paths for every range (and `ranged_from` in all); other roots are cut into spans
+// (k_cycle4_heavy) from `heavy_from` two-paths on, and below that one workgroup walks them (k_cycle4_light).
+struct CycRule {
+    int64_t heavy_from, ranged_from;
+    int32_t S, per_range;  // S = 0: no root counts in LDS
+};
+__host__ __device__ __forceinline__ bool cyc_is_ranged(const CycRule &rule, int64_t paths, int32_t v1) {
+    if (!rule.S || paths < rule.ranged_from) return false;
+    return paths >= (int64_t)rule.per_range * (((int64_t)v1 + rule.S - 1) / rule.S);
+}
+__host__ __device__ __forceinline__ bool cyc_is_heavy(const CycRule &rule, int64_t paths, int32_t v1) {
+    return paths >= rule.heavy_from || cyc_is_ranged(rule, paths, v1);
+}
+
 // Light roots: one workgroup of 4 waves per root, roots taken from a queue
 // (index order = heaviest first); workgroup b owns the counter array
-// dense + b * stride.  Roots whose cost exceeds heavy_thr
+// dense + b * stride.  Roots that `rule` calls heavy
 // are left to k_cycle4_heavy.
 #define CYC_HEAVY_GROUPS 3  // groups of counter arrays for heavy roots, one group per stream
 __global__ __launch_bounds__(256) void k_cycle4_light(GraphView g, const int64_t *wp, int64_t lo, int64_t hi,
-                                                      const int64_t *cost, int64_t heavy_thr,
+                                                      const int64_t *cost, CycRule rule,
                                                       unsigned long long *queue, uint32_t *dense, int64_t stride,
                                                       unsigned long long *n_cycles, unsigned long long *alg_bytes) {
     __shared__ uint32_t s_pre[4][GPM_WAVE];
@@ -2291,7 +2315,7 @@ __global__ __launch_bounds__(256) void k_cycle4_light(GraphView g, const int64_t
             }
         }
         const int64_t paths = cost[i] - 1;
-        if (paths >= heavy_thr || paths < 2 || (batch > 1 && paths <= GPM_WAVE)) {  // a cycle needs two two-paths
+        if (paths < 2 || (batch > 1 && paths <= GPM_WAVE) || cyc_is_heavy(rule, paths, (int32_t)(g.n - 1 - i))) {  // a cycle needs two two-paths
             ++i;
             continue;
         }
@@ -2378,6 +2402,155 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_heavy(Grap
         const int64_t lb = g.off[0][v1], le = g.mid[0][v1];
         bytes = 8ull * (uint64_t)(wp[le] - wp[lb]) + 4ull + 12ull * (uint64_t)(le - lb);
     }
+    acc = wave_sum_u64(acc);
+    if (lane == 0 && acc) atomicAdd(n_cycles, (unsigned long long)acc);
+    if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
+}
+
+// Heavy roots with counters held in LDS.  A random 4-byte atomic on a counter
+// array in global memory costs a whole cache line of traffic for every cold
+// counter and queues on every hot one.  Here the counters of root v1 are cut
+// into ranges of S ids counted down from v1 (range q covers
+// [v1 - (q + 1) S, v1 - q S) below v1, so the range next to v1 -- the highest
+// degrees, the hottest counters -- is always a full one) and a workgroup of 16
+// waves keeps the S counters of one range at a time in LDS.  Its task is one
+// block of 1024 * tiles arcs v1 -> v2 below v1, one arc per lane and
+// `tiles` (at most CYC_RANGE_TILES) tiles of 64 arcs per wave, and it takes the ranges from the
+// top down: lists are ascending, so the two-paths v1 - v2 - v3 with v3 inside
+// a range are one contiguous piece of N(v2) that ends where the piece of the
+// range above began -- every lane keeps that position and finds the piece's
+// start by galloping backwards from it (pieces are short: a probe or two, in
+// the cache line just read).  A wave scan of the piece lengths concatenates a
+// tile's 64 pieces, lanes take consecutive two-paths of the concatenation and
+// add 1 to the LDS counter of v3; the old values add up to sum k(k-1)/2 over
+// the range's counters.  A root with one block is done with that.  With
+// several blocks every task then adds its non-zero counters k to the root's
+// array in global memory (root r of the batch: dense + r * stride, zeroed by
+// the caller afterwards), and an old value o there stands for o * k more
+// pairs: at most S atomics per task and range instead of one per two-path,
+// all inside one 4 S-byte piece of the array.  A task ends with the range in
+// which its last list runs out.
+// Workgroups wg0[r] .. wg0[r + 1] are the arc blocks of root r of the batch;
+// with an empty batch workgroup i is the only block of root singles[i] (any
+// number of roots per launch, the list lives in global memory).
+// Dynamic LDS (words): cnt[S] | s_beg[16][64] (int64) | s_pre[16][64].
+#define CYC_RANGE_MAX_IDS 32768
+#define CYC_RANGE_TILES 4
+#define CYC_RANGE_LDS_BYTES(S) ((S) * 4 + CYC_HEAVY_WAVES * GPM_WAVE * 12)
+
+__global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(GraphView g, const int64_t *wp, CycBatch b,
+                                                                            const int32_t *singles, int S, int tiles,
+                                                                            uint32_t *dense, int64_t stride,
+                                                                            unsigned long long *n_cycles,
+                                                                            unsigned long long *alg_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *cnt = smem;
+    const int wave = threadIdx.x / GPM_WAVE, lane = lane_id();
+    int64_t *s_beg = reinterpret_cast<int64_t *>(smem + S) + wave * GPM_WAVE;  // S is a multiple of 4
+    uint32_t *s_pre = smem + S + CYC_HEAVY_WAVES * GPM_WAVE * 2 + wave * GPM_WAVE;
+    int r = 0;  // last root with wg0[r] <= blockIdx.x
+    for (int hi = b.n; hi - r > 1;) {
+        const int m = (r + hi) >> 1;
+        if (b.wg0[m] <= (int)blockIdx.x) r = m;
+        else hi = m;
+    }
+    const int32_t v1 = b.n ? b.v1[r] : singles[blockIdx.x];
+    const int64_t *off = g.off[0];
+    const int32_t *adj = g.adj[0];
+    const int64_t lb = off[v1], le = g.mid[0][v1];
+    const int blk = b.n ? (int)blockIdx.x - b.wg0[r] : 0;
+    const bool merge = b.n && b.wg0[r + 1] - b.wg0[r] > 1;
+    // this lane's arcs: tile k * 16 + wave of the block; lo[k] .. lo[k] + left[k] is what is left of N(v2)
+    // below the ranges done so far (at first: below v1, the arc's two-path count)
+    int64_t lo[CYC_RANGE_TILES];
+    uint32_t left[CYC_RANGE_TILES];
+    bool more = false;
+#pragma unroll
+    for (int k = 0; k < CYC_RANGE_TILES; ++k) {
+        const int64_t a = lb + ((int64_t)blk * tiles + k) * (CYC_HEAVY_WAVES * GPM_WAVE) + wave * GPM_WAVE + lane;
+        lo[k] = 0;
+        left[k] = 0;
+        if (k < tiles && a < le) {
+            lo[k] = off[adj[a]];
+            left[k] = (uint32_t)(wp[a + 1] - wp[a]);
+        }
+        more |= left[k] != 0;
+    }
+    uint64_t acc = 0;
+    for (int32_t id_hi = v1; __syncthreads_or(more); id_hi -= S) {  // the barrier also ends the last range's flush
+        const int32_t id_lo = max(0, id_hi - S);  // this pass counts the v3 in [id_lo, id_hi)
+        for (int x = threadIdx.x; x < S / 4; x += blockDim.x) reinterpret_cast<uint4 *>(cnt)[x] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        more = false;
+        // first entry of what is left that lies in the range: backwards in doubling steps while the entry
+        // is still inside, then a binary search in the last step.  The last entries of all tiles are
+        // requested together: most lists have nothing in a range, and that is known after one read.
+        uint32_t keeps[CYC_RANGE_TILES];  // entries that stay for the ranges below
+        bool inside[CYC_RANGE_TILES];
+#pragma unroll
+        for (int k = 0; k < CYC_RANGE_TILES; ++k) {
+            keeps[k] = left[k];
+            inside[k] = left[k] != 0 && adj[lo[k] + left[k] - 1] >= id_lo;
+        }
+#pragma unroll
+        for (int k = 0; k < CYC_RANGE_TILES; ++k) {
+            uint32_t keep = keeps[k];
+            if (inside[k]) {
+                const int32_t *list = adj + lo[k];
+                keep -= 1;
+                uint32_t step = 2;
+                while (keep >= step && list[keep - step] >= id_lo) {
+                    keep -= step;
+                    step <<= 1;
+                }
+                uint32_t b0 = keep >= step ? keep - step + 1 : 0;  // list[b0 - 1] < id_lo (or b0 == 0), list[keep] >= id_lo
+                while (b0 < keep) {
+                    const uint32_t m = (b0 + keep) >> 1;
+                    if (list[m] < id_lo) b0 = m + 1;
+                    else keep = m;
+                }
+            }
+            const uint32_t len = left[k] - keep;
+            const int64_t beg = lo[k] + keep;
+            left[k] = keep;
+            more |= keep != 0;
+            const uint32_t incl = wave_incl_scan_u32(len);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, GPM_WAVE - 1);
+            if (total == 0) continue;
+            wave_lds_sync();
+            s_pre[lane] = incl - len;  // arcs without a piece share the prefix of the next arc that has one
+            s_beg[lane] = beg;
+            wave_lds_sync();
+            for (uint32_t w0 = 0; w0 < total; w0 += 4 * GPM_WAVE) {
+                int32_t v3[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t w = w0 + u * GPM_WAVE + lane;
+                    v3[u] = -1;
+                    if (w < total) {
+                        int j = 0;  // last arc of the tile with s_pre[j] <= w
+#pragma unroll
+                        for (int st = GPM_WAVE / 2; st > 0; st >>= 1)
+                            if (s_pre[j + st] <= w) j += st;
+                        v3[u] = adj[s_beg[j] + (w - s_pre[j])];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (v3[u] >= 0) acc += atomicAdd(cnt + (v3[u] - id_lo), 1u);
+            }
+        }
+        if (merge) {  // this block's counts meet those of the root's other blocks
+            __syncthreads();
+            uint32_t *shared_cnt = dense + (size_t)r * (size_t)stride + id_lo;
+            for (int x = threadIdx.x; x < id_hi - id_lo; x += blockDim.x) {
+                const uint32_t k = cnt[x];
+                if (k) acc += (uint64_t)atomicAdd(shared_cnt + x, k) * k;
+            }
+        }
+    }
+    uint64_t bytes = 0;
+    if (blk == 0 && threadIdx.x == 0) bytes = 8ull * (uint64_t)(wp[le] - wp[lb]) + 4ull + 12ull * (uint64_t)(le - lb);
     acc = wave_sum_u64(acc);
     if (lane == 0 && acc) atomicAdd(n_cycles, (unsigned long long)acc);
     if (bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);

@@ -138,7 +138,14 @@ LARGE_PATHS = {
                  ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_KAPPA4": "-1"}, False, (KIND_CLQ_BUILD,)),
                  ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_KAPPA4": "0"}, False, (KIND_CLQ_BUILD,)),
                  ({"GPM_CLIQUE_SMALL_MAX": "24"}, False, (KIND_CLQ_BUILD,))],
-    "cycle4": [({}, True, (KIND_CYCLE4,)), ({"GPM_CYCLE4_HEAVY": "4096"}, True, (KIND_CYCLE4,))],
+    # heavy roots as spans of two-paths on counter arrays in global memory; the heaviest with their counters
+    # in LDS, one workgroup per range of ids (dozens of narrow ranges) and, with several arc blocks per root,
+    # the blocks' counts merged through the root's array in global memory
+    "cycle4": [({}, True, (KIND_CYCLE4,)), ({"GPM_CYCLE4_HEAVY": "4096", "GPM_CYC_RANGES": "0"}, True, (KIND_CYCLE4,)),
+               ({"GPM_CYCLE4_HEAVY": "4096", "GPM_CYC_RANGES_FROM": "100000000"}, True, (KIND_CYCLE4,)),
+               ({"GPM_CYC_RANGES_FROM": "1024", "GPM_CYC_RANGE_WORK": "0", "GPM_CYC_RANGE_IDS": "256"}, True, (KIND_CYCLE4,)),
+               ({"GPM_CYC_RANGES_FROM": "1024", "GPM_CYC_RANGE_WORK": "0", "GPM_CYC_RANGE_IDS": "1024",
+                 "GPM_CYC_RANGE_TILES": "1"}, True, (KIND_CYCLE4,))],
 }
 
 
@@ -152,7 +159,8 @@ def test_large_goldens(spec, monkeypatch):
     dl, pl = util.build_labels(spec, n)
     for env, accounting, kinds in LARGE_PATHS.get(spec["pattern"], [({}, True, ())]):
         for k in ("GPM_CLIQUE_SMALL_MAX", "GPM_CLQ_LISTS_MAX_CLASS", "GPM_COUNT4_WAVES", "GPM_CYCLE4_HEAVY", "GPM_CLQ_KAPPA4",
-                  "GPM_CLQ_LISTS_WAVES", "GPM_CLIQUE_TINY"):
+                  "GPM_CLQ_LISTS_WAVES", "GPM_CLIQUE_TINY", "GPM_CYC_RANGE_IDS", "GPM_CYC_RANGES",
+                  "GPM_CYC_RANGES_FROM", "GPM_CYC_RANGE_TILES", "GPM_CYC_RANGE_WORK"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -356,16 +364,24 @@ def test_two_path_counting_of_four_cycles_equals_the_generic_path(monkeypatch):
     want = m.findMatches(count_only=True)
     m.close()
     monkeypatch.delenv("GPM_NO_CYCLE4")
-    monkeypatch.setenv("GPM_CYCLE4_HEAVY", "100000")
-    m = binding.Matcher(1)
-    m.upload(n, o, a)
-    m.set_pattern(gen.PATTERNS["cycle4"])
-    for chunks in (1, 8, 64, 4000):
-        m.set_chunks(chunks)
-        assert m.findMatches(count_only=True) == want, chunks
-    st = m.stats()
-    assert st.kernel_launches[5] > 0  # GPM_KIND_CYCLE4
-    m.close()
+    # heavy roots: counters in LDS for roots with enough two-paths per range of ids (the default); for every
+    # root from 5000 two-paths on, in 64 narrow ranges, with the counts of several arc blocks per root merged
+    # through its array in global memory; spans on global counter arrays
+    for env in ({}, {"GPM_CYC_RANGES_FROM": "5000", "GPM_CYC_RANGE_WORK": "0", "GPM_CYC_RANGE_IDS": "1024", "GPM_CYC_RANGE_TILES": "1"},
+                {"GPM_CYC_RANGES": "0", "GPM_CYCLE4_HEAVY": "100000"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = binding.Matcher(1)
+        m.upload(n, o, a)
+        m.set_pattern(gen.PATTERNS["cycle4"])
+        for chunks in (1, 8, 64, 4000):
+            m.set_chunks(chunks)
+            assert m.findMatches(count_only=True) == want, (env, chunks)
+        st = m.stats()
+        assert st.kernel_launches[5] > 0  # GPM_KIND_CYCLE4
+        m.close()
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 @pytest.mark.parametrize("hub_rows", [None, "0"], ids=["hub_matrix", "hashed_lists"])
