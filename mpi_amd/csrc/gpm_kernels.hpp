@@ -2414,7 +2414,7 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_heavy(Grap
 // [v1 - (q + 1) S, v1 - q S) below v1, so the range next to v1 -- the highest
 // degrees, the hottest counters -- is always a full one) and a workgroup of 16
 // waves keeps the S counters of one range at a time in LDS.  Its task is one
-// block of 1024 * tiles arcs v1 -> v2 below v1, one arc per lane and
+// block of up to 1024 * tiles arcs v1 -> v2 below v1, one arc per lane and
 // `tiles` (at most CYC_RANGE_TILES) tiles of 64 arcs per wave, and it takes the ranges from the
 // top down: lists are ascending, so the two-paths v1 - v2 - v3 with v3 inside
 // a range are one contiguous piece of N(v2) that ends where the piece of the
@@ -2444,6 +2444,7 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
                                                                             unsigned long long *n_cycles,
                                                                             unsigned long long *alg_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ int32_t s_top[2];
     uint32_t *cnt = smem;
     const int wave = threadIdx.x / GPM_WAVE, lane = lane_id();
     int64_t *s_beg = reinterpret_cast<int64_t *>(smem + S) + wave * GPM_WAVE;  // S is a multiple of 4
@@ -2459,43 +2460,53 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
     const int32_t *adj = g.adj[0];
     const int64_t lb = off[v1], le = g.mid[0][v1];
     const int blk = b.n ? (int)blockIdx.x - b.wg0[r] : 0;
-    const bool merge = b.n && b.wg0[r + 1] - b.wg0[r] > 1;
-    // this lane's arcs: tile k * 16 + wave of the block; lo[k] .. lo[k] + left[k] is what is left of N(v2)
-    // below the ranges done so far (at first: below v1, the arc's two-path count)
+    const int nblk = b.n ? b.wg0[r + 1] - b.wg0[r] : 1;
+    const bool merge = nblk > 1;
+    // This lane's arcs.  Neighbouring arcs (similar ids, so similar degrees: the last arcs of a hub lead
+    // to the other hubs, whose lists are the longest) go to different blocks first, then to different
+    // waves, then to different lanes, so that every block and every wave gets its share of the long lists.
+    // lo[k] .. lo[k] + left[k] is what is left of N(v2) below the ranges done so far (at first: below v1,
+    // the arc's two-path count)
     int64_t lo[CYC_RANGE_TILES];
     uint32_t left[CYC_RANGE_TILES];
-    bool more = false;
 #pragma unroll
     for (int k = 0; k < CYC_RANGE_TILES; ++k) {
-        const int64_t a = lb + ((int64_t)blk * tiles + k) * (CYC_HEAVY_WAVES * GPM_WAVE) + wave * GPM_WAVE + lane;
+        const int64_t a = lb + ((int64_t)((k * GPM_WAVE + lane) * CYC_HEAVY_WAVES + wave)) * nblk + blk;
         lo[k] = 0;
         left[k] = 0;
         if (k < tiles && a < le) {
             lo[k] = off[adj[a]];
             left[k] = (uint32_t)(wp[a + 1] - wp[a]);
         }
-        more |= left[k] != 0;
     }
+    if (threadIdx.x == 0) s_top[0] = s_top[1] = -1;
     uint64_t acc = 0;
-    for (int32_t id_hi = v1; __syncthreads_or(more); id_hi -= S) {  // the barrier also ends the last range's flush
-        const int32_t id_lo = max(0, id_hi - S);  // this pass counts the v3 in [id_lo, id_hi)
-        for (int x = threadIdx.x; x < S / 4; x += blockDim.x) reinterpret_cast<uint4 *>(cnt)[x] = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
-        more = false;
-        // first entry of what is left that lies in the range: backwards in doubling steps while the entry
-        // is still inside, then a binary search in the last step.  The last entries of all tiles are
-        // requested together: most lists have nothing in a range, and that is known after one read.
-        uint32_t keeps[CYC_RANGE_TILES];  // entries that stay for the ranges below
-        bool inside[CYC_RANGE_TILES];
+    for (int pass = 0;; ++pass) {
+        __syncthreads();  // the last pass is over (walk and flush), s_top[pass & 1] is -1
+        // The last entry of every list that has entries left, all tiles requested together; the highest
+        // of them over the workgroup is where this pass's range ends, so no pass is spent on ids nobody has
+        // left, and a list has entries in the range exactly when its last entry is at or above id_lo.
+        int32_t last[CYC_RANGE_TILES];
+        int32_t top = -1;
 #pragma unroll
         for (int k = 0; k < CYC_RANGE_TILES; ++k) {
-            keeps[k] = left[k];
-            inside[k] = left[k] != 0 && adj[lo[k] + left[k] - 1] >= id_lo;
+            last[k] = left[k] ? adj[lo[k] + left[k] - 1] : -1;
+            top = max(top, last[k]);
         }
+        for (int x = threadIdx.x; x < S / 4; x += blockDim.x) reinterpret_cast<uint4 *>(cnt)[x] = make_uint4(0u, 0u, 0u, 0u);
+        for (int o = 32; o > 0; o >>= 1) top = max(top, __shfl_xor(top, o, GPM_WAVE));
+        if (lane == 0 && top >= 0) atomicMax(&s_top[pass & 1], top);
+        __syncthreads();
+        const int32_t id_hi = s_top[pass & 1] + 1;
+        if (id_hi <= 0) break;  // every list has run out
+        if (threadIdx.x == 0) s_top[(pass & 1) ^ 1] = -1;  // read last before the barrier at the top of this pass
+        const int32_t id_lo = max(0, id_hi - S);  // this pass counts the v3 in [id_lo, id_hi)
 #pragma unroll
         for (int k = 0; k < CYC_RANGE_TILES; ++k) {
-            uint32_t keep = keeps[k];
-            if (inside[k]) {
+            // first entry of what is left that lies in the range: backwards in doubling steps while the
+            // entry is still inside, then a binary search in the last step
+            uint32_t keep = left[k];  // entries that stay for the ranges below
+            if (last[k] >= id_lo) {
                 const int32_t *list = adj + lo[k];
                 keep -= 1;
                 uint32_t step = 2;
@@ -2513,7 +2524,6 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
             const uint32_t len = left[k] - keep;
             const int64_t beg = lo[k] + keep;
             left[k] = keep;
-            more |= keep != 0;
             const uint32_t incl = wave_incl_scan_u32(len);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, GPM_WAVE - 1);
             if (total == 0) continue;
