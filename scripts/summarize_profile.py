@@ -22,7 +22,7 @@ SEARCH = ("k_clique", "k_clq_", "k_cycle4", "k_tail", "k_leaf_pair", "k_extend",
           "k_sum_slots")
 # kernel family (the names gpm_hip_kernel_name returns) -> prefixes of the kernels in it
 FAMILIES = {"k_tail": ("k_tail", "k_leaf_pair"), "k_extend": ("k_extend",), "k_clique": ("k_clique<", "k_clique_tiny<"),
-            "k_clq_build": ("k_clq_build",), "k_clq_count4": ("k_clq_count4",), "k_cycle4": ("k_cycle4_light", "k_cycle4_heavy")}
+            "k_clq_build": ("k_clq_build",), "k_clq_count4": ("k_clq_count4",), "k_cycle4": ("k_cycle4_light", "k_cycle4_heavy", "k_cycle4_ranges")}
 
 
 def fingerprint():
@@ -119,7 +119,10 @@ SEARCHES = 3
 traffic["searches_profiled"] = SEARCHES
 traffic["valu_wave_instructions_per_search"] = sum(v["SQ_INSTS_VALU"] for v in summary.values()) / SEARCHES
 traffic["hbm_bytes_per_search"] = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in summary.values()) / SEARCHES
-with open(os.path.join(dst, "hbm_traffic.json"), "w") as f:
+# the headline workload's traffic is what bench.py reads; other workloads (tags that name a configuration,
+# e.g. r2_config2) keep theirs beside their own summary
+traffic_name = "hbm_traffic.json" if "config" not in tag else f"{tag}_hbm_traffic.json"
+with open(os.path.join(dst, traffic_name), "w") as f:
     json.dump(traffic, f, indent=1)
     f.write("\n")
 for name in ("trace.json",):
