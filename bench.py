@@ -376,8 +376,12 @@ def main():
         dom_bytes_per_step = k_bytes[dom] * share
         achieved = (dom_bytes_per_step * steps / 1e9) / (k_ms[dom] / 1e3) if k_ms[dom] > 0 else 0.0
         traffic, traffic_note, tj = None, "no committed counter pass", {}
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from the committed PMC passes, per kernel family
+        # the counter passes are of one GPU running a configuration at its own size: hbm_traffic.json for the
+        # headline workload, config<N>_hbm_traffic.json for the others
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json" if args.config == 3 else f"config{args.config}_hbm_traffic.json")
+        if overridden or world > 1:
+            traffic_note = "committed counter passes are of the single-GPU run at the configuration's size: not reported"
+        elif os.path.exists(tpath):  # HBM bytes per launch from the committed PMC passes, per kernel family
             with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("kernels_fingerprint") == kernels_fingerprint():

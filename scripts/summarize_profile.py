@@ -119,9 +119,11 @@ SEARCHES = 3
 traffic["searches_profiled"] = SEARCHES
 traffic["valu_wave_instructions_per_search"] = sum(v["SQ_INSTS_VALU"] for v in summary.values()) / SEARCHES
 traffic["hbm_bytes_per_search"] = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in summary.values()) / SEARCHES
-# the headline workload's traffic is what bench.py reads; other workloads (tags that name a configuration,
-# e.g. r2_config2) keep theirs beside their own summary
-traffic_name = "hbm_traffic.json" if "config" not in tag else f"{tag}_hbm_traffic.json"
+# bench.py reads hbm_traffic.json for the headline workload (configuration 3) and config<N>_hbm_traffic.json
+# for the others: a tag that names a configuration (e.g. r2_config2) writes the latter
+import re
+cfg_tag = re.search(r"config(\d+)", tag)
+traffic_name = f"config{cfg_tag.group(1)}_hbm_traffic.json" if cfg_tag else "hbm_traffic.json"
 with open(os.path.join(dst, traffic_name), "w") as f:
     json.dump(traffic, f, indent=1)
     f.write("\n")
