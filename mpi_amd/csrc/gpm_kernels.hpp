@@ -1258,7 +1258,81 @@ __global__ __launch_bounds__(BLOCK) void k_clique(GraphView g, const int32_t *ro
 
         // ---- build the rows: row i = N+(U[i]) ^ U, as bits over positions in U
         uint64_t arcs_bytes = 0;  // per lane: sum over its arcs i->j of 12 + 4*(d + Dp[i] + Dp[j])
-        for (int i = wave; i < d; i += NW) {
+        // The hub rows of a universe of at most 256 vertices: a row has positions to test only in the blocks
+        // of 64 from the one that holds i + 1 on.  The (row, block)
+        // pairs that hold something are therefore numbered block by block -- block b is tested by the rows
+        // 0 .. min(d, 64 b + 63) - 1 -- and a wave takes four of them per trip, whichever rows they belong
+        // to: four useful gathers in flight per trip instead of one to four (one for most rows of a small
+        // universe).
+        // U ascends, so its hubs are its last vertices: rows h0 .. d - 1 are packed, the rows before them walk
+        // their lists below.
+        const bool packed = probe_bias == 0 && g.hub != nullptr && d <= CLQ_GATHERS * GPM_WAVE;
+        int h0 = d;  // first position of U that holds a hub
+        if (packed) {
+            int lo = 0;
+            while (lo < h0) {
+                const int m = (lo + h0) >> 1;
+                if (U[m] < g.hub_base) lo = m + 1;
+                else h0 = m;
+            }
+        }
+        if (packed && h0 < d) {
+            const int nb = (d + GPM_WAVE - 1) / GPM_WAVE;
+            int first[CLQ_GATHERS + 1];  // number of the first pair of block b
+            first[0] = 0;
+#pragma unroll
+            for (int bk = 0; bk < CLQ_GATHERS; ++bk)
+                first[bk + 1] = first[bk] + (bk < nb ? max(0, min(d, GPM_WAVE * bk + GPM_WAVE - 1) - h0) : 0);
+            const int pairs = first[CLQ_GATHERS];
+            // the words no pair writes are zeros: blocks below the one that holds i + 1, blocks past d
+            const int wsh = Wp == 4 ? 2 : 3;  // Wp is 4 or 8 up to 256 vertices
+            for (int x = tid + (h0 << wsh); x < (d << wsh); x += BLOCK) {
+                const int i = x >> wsh, blk = (x & (Wp - 1)) >> 1;
+                if (blk < ((i + 1) >> 6) || blk >= nb) rows[x] = 0;
+            }
+            for (int t0 = CLQ_GATHERS * wave; t0 < pairs; t0 += CLQ_GATHERS * NW) {
+                uint32_t word[CLQ_GATHERS], sh[CLQ_GATHERS], col[CLQ_GATHERS], sum[CLQ_GATHERS];
+                bool live[CLQ_GATHERS];
+                int row_of[CLQ_GATHERS], blk_of[CLQ_GATHERS];
+#pragma unroll
+                for (int k = 0; k < CLQ_GATHERS; ++k) {
+                    const int t = min(t0 + k, max(pairs, 1) - 1);  // a trip past the end repeats the last pair, and drops it below
+                    const int bk = (t >= first[1]) + (t >= first[2]) + (t >= first[3]);
+                    const int i = h0 + t - first[bk];
+                    row_of[k] = i;
+                    blk_of[k] = bk;
+                    const int j = bk * GPM_WAVE + lane;
+                    live[k] = t0 + k < pairs && j > i && j < d;
+                    col[k] = live[k] ? (uint32_t)(U[j] - g.hub_base) : 0u;
+                    sum[k] = 0;
+                    word[k] = 0;
+                    sh[k] = col[k] & 31;
+                    if (live[k]) {
+                        const size_t hr = (size_t)(U[i] - g.hub_base);
+                        if (col[k] >= (uint32_t)g.hub_dense || !g.hubc) word[k] = g.hub[hr * (size_t)g.hub_wpr + (col[k] >> 5)];
+                        else sum[k] = g.hubc[hr * (size_t)g.hub_cwpr + (col[k] >> 10)];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < CLQ_GATHERS; ++k)
+                    if ((sum[k] >> ((col[k] >> 5) & 31)) & 1u)
+                        word[k] = g.hub[(size_t)(U[row_of[k]] - g.hub_base) * (size_t)g.hub_wpr + (col[k] >> 5)];
+#pragma unroll
+                for (int k = 0; k < CLQ_GATHERS; ++k) {
+                    if (t0 + k >= pairs) break;
+                    const bool bit = live[k] && ((word[k] >> sh[k]) & 1u);
+                    unsigned long long mask = __ballot(bit);
+                    if (STATS && bit)
+                        arcs_bytes += 12ull + 4ull * ((uint64_t)d + Dp[row_of[k]]) + 4ull * Dp[blk_of[k] * GPM_WAVE + lane];
+                    if (lane == 0) {
+                        uint32_t *row = rows + ((size_t)row_of[k] << wsh) + 2 * blk_of[k];
+                        row[0] = (uint32_t)mask;
+                        row[1] = (uint32_t)(mask >> 32);
+                    }
+                }
+            }
+        }
+        for (int i = wave; i < h0; i += NW) {
             const int32_t v = U[i];
             uint32_t *row = rows + (size_t)i * Wp;
             const uint64_t per_arc = STATS ? 12ull + 4ull * ((uint64_t)d + Dp[i]) : 0ull;
