@@ -751,7 +751,7 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
     d.gv.label = d.label;
 
     // hub matrix over the highest-degree vertices (the last ids after renumbering)
-    int64_t hub_rows = std::min<int64_t>(env_i64("GPM_HUB_ROWS", (int64_t)1 << 18), ((int64_t)n + 63) / 64 * 64);
+    int64_t hub_rows = std::min<int64_t>(env_i64("GPM_HUB_ROWS", (int64_t)1 << 19), ((int64_t)n + 63) / 64 * 64);
     hub_rows = std::max<int64_t>(0, hub_rows / 64 * 64);
     d.gv.hub_base = n;
     d.gv.hub_wpr = 0;
