@@ -2008,7 +2008,8 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
                                                     const uint32_t *rows_buf, int64_t stride_words,
                                                     unsigned long long *n_matches) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
+    // the wave number read as a scalar: row numbers, row addresses and loop tests then stay out of the vector unit
+    const int tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid / GPM_WAVE);
     const int tcap = dcap > 1024 ? dcap >> 10 : 1;  // column tiles a root of this class can have
     const int phases = tcap * (tcap + 1) / 2;        // tile pairs (a, b), a <= b
     const int64_t ri = blockIdx.x / (phases * SEG);
