@@ -50,10 +50,17 @@ CONFIGS = {
         "twin": {"graph": "rmat", "scale": 9, "ef": 8, "abcd": (0.7, 0.1, 0.1, 0.1), "seed": 1}},
 }
 
-# Embeddings of every configuration at full size.  No CPU program can enumerate them; they are what the
-# independent device paths agree on (bitmap / two-path / closed-form kernels against the level-by-level
-# kernels), and the same kernels reproduce the captured vectors of tests/golden at the sizes a CPU can reach.
+# Embeddings of every configuration at full size.  No CPU program can enumerate them.  The clique
+# configurations (1 and 3) are pinned by an independent count on the CPU (oracle/clique_count.c, a checker that
+# shares nothing with the HIP library and is itself pinned to the reference's vectors;
+# tests/golden/full_size_counts.json, tests/test_clique_count.py).  The others are what the independent device
+# paths agree on (two-path / closed-form kernels against the level-by-level kernels), and the same kernels
+# reproduce the captured vectors of tests/golden at the sizes a CPU can reach.
 EXPECTED_FULL = {1: 924, 2: 3614591580112, 3: 21123390052368, 4: 20278778911046, 5: 235455970772256}
+EXPECTED_FULL_SOURCE = {
+    1: "independent CPU count (oracle/clique_count.c), tests/golden/full_size_counts.json",
+    3: "independent CPU count (oracle/clique_count.c), tests/golden/full_size_counts.json",
+}
 
 
 def spec_key(graph, pattern, labels=None, pattern_labels=None):
@@ -65,7 +72,8 @@ def spec_key(graph, pattern, labels=None, pattern_labels=None):
 def expected_count(config, cfg, overridden, labelled):
     """(count, where it comes from) for the workload about to run, or (None, None)."""
     if not overridden:
-        return EXPECTED_FULL[config], "count the device paths agree on at full size (bench.py EXPECTED_FULL)"
+        return EXPECTED_FULL[config], EXPECTED_FULL_SOURCE.get(
+            config, "count the device paths agree on at full size (bench.py EXPECTED_FULL)")
     want = spec_key(cfg["graph"], cfg["pattern"], cfg.get("labels") if labelled else None,
                     cfg.get("pattern_labels") if labelled else None)
     for name in ("golden.json", "golden_large.json"):
