@@ -1,4 +1,4 @@
-/* Independent count of triangles and 4-cliques of a large simple undirected graph.
+/* Independent count of triangles, 4-cliques and 4-cycles of a large simple undirected graph.
  *
  * TEST INFRASTRUCTURE, like the rest of oracle/: nothing on the product path may
  * link or run it.  It exists to pin the counts that the benchmark prints at sizes
@@ -19,9 +19,15 @@
  * above member i adjacent to it), triangles are the set bits, 4-cliques the sum
  * over set bits j of row i of |row_i AND row_j|.  Roots are spread over threads.
  *
+ * 4-cycles (k = -4 on the command line: "c4").  A 4-cycle x - v - y - v' - x has one highest vertex x in the
+ * same order and one vertex y opposite to it; with c(x, y) = number of common neighbours of x and y that lie
+ * below x, the cycles with highest vertex x number the sum over y below x of c(c-1)/2.  The pattern with its
+ * 8 arcs has 8 automorphisms, so the reference finds each cycle 8 times.  Per root x one array of counters
+ * indexed by y is filled by walking the lists of x's lower neighbours, summed and cleared the same way.
+ *
  * Input: a binary file  int64 n, int64 m, int64 off[n + 1], int32 adj[m]
  * (symmetric, no self loops, no duplicates, 0-based; list order is free).
- * usage: clique_count <file> <k = 3 | 4> [threads]
+ * usage: clique_count <file> <3 | 4 | c4> [threads]
  */
 #include <inttypes.h>
 #include <pthread.h>
@@ -60,7 +66,22 @@ static void *worker(void *arg) {
         int64_t u0 = __sync_fetch_and_add(&next_root, 4096);
         if (u0 >= n) break;
         int64_t u1 = u0 + 4096 < n ? u0 + 4096 : n;
-        for (int64_t u = u0; u < u1; ++u) {
+        for (int64_t u = u0; u < u1 && kk == -4; ++u) {  /* 4-cycles: u is the highest vertex, pos[] counts */
+            for (int64_t p = off[u]; p < off[u + 1]; ++p) {
+                const int32_t v = adj[p];
+                if (!lower(v, (int32_t)u)) continue;
+                for (int64_t q = off[v]; q < off[v + 1]; ++q) {
+                    const int32_t y = adj[q];
+                    if (y != u && lower(y, (int32_t)u)) mine += (unsigned)(++pos[y]);  /* -1 + 1 = 0 first: old values add up to c(c-1)/2 */
+                }
+            }
+            for (int64_t p = off[u]; p < off[u + 1]; ++p) {
+                const int32_t v = adj[p];
+                if (!lower(v, (int32_t)u)) continue;
+                for (int64_t q = off[v]; q < off[v + 1]; ++q) pos[adj[q]] = -1;
+            }
+        }
+        for (int64_t u = u0; u < u1 && kk != -4; ++u) {
             const int64_t b = poff[u], d = poff[u + 1] - b;
             if (d < kk - 1) continue;
             for (int64_t i = 0; i < d; ++i) pos[padj[b + i]] = (int32_t)i;
@@ -131,13 +152,13 @@ static void print_u128(unsigned __int128 v) {
 
 int main(int argc, char **argv) {
     if (argc < 3) {
-        fprintf(stderr, "usage: clique_count <csr file> <3|4> [threads]\n");
+        fprintf(stderr, "usage: clique_count <csr file> <3|4|c4> [threads]\n");
         return 2;
     }
-    kk = atoi(argv[2]);
+    kk = strcmp(argv[2], "c4") == 0 ? -4 : atoi(argv[2]);
     nthreads = argc > 3 ? atoi(argv[3]) : 8;
-    if ((kk != 3 && kk != 4) || nthreads < 1 || nthreads > 256) {
-        fprintf(stderr, "clique_count: k must be 3 or 4, threads 1..256\n");
+    if ((kk != 3 && kk != 4 && kk != -4) || nthreads < 1 || nthreads > 256) {
+        fprintf(stderr, "clique_count: pattern must be 3, 4 or c4, threads 1..256\n");
         return 2;
     }
     FILE *f = fopen(argv[1], "rb");
@@ -171,7 +192,8 @@ int main(int argc, char **argv) {
     for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
     unsigned __int128 emb = total;
     for (int i = 2; i <= kk; ++i) emb *= (unsigned)i;
-    printf("{\"k\": %d, \"cliques\": ", kk);
+    if (kk == -4) emb = total * 8;
+    printf("{\"k\": %d, \"%s\": ", kk == -4 ? 4 : kk, kk == -4 ? "cycles" : "cliques");
     print_u128(total);
     printf(", \"embeddings\": ");
     print_u128(emb);

@@ -1,4 +1,4 @@
-"""Counts of the benchmark's clique configurations at FULL size from the independent counter
+"""Counts of the benchmark's clique and 4-cycle configurations at FULL size from the independent counter
 (oracle/clique_count.c: degree orientation + bit rows on the CPU, no code or layout shared with the HIP
 library), written to tests/golden/full_size_counts.json.  The reference cannot run these sizes (its 500 MB
 per rank budget, reference: src/gpm-par.c:303-337, and days of run time); the counter is pinned to the
@@ -25,7 +25,7 @@ from mpi_amd import gen  # noqa: E402
 import bench  # noqa: E402
 
 BIN = os.path.join(ROOT, "oracle", "_build", "clique_count")
-K = {"triangle": 3, "clique4": 4}
+K = {"triangle": "3", "clique4": "4", "cycle4": "c4"}
 
 
 def main():
