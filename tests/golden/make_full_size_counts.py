@@ -1,4 +1,4 @@
-"""Counts of the benchmark's clique and 4-cycle configurations at FULL size from the independent counter
+"""Counts of the benchmark's clique, 4-cycle and labelled-tree configurations at FULL size from independent counters
 (oracle/clique_count.c: degree orientation + bit rows on the CPU, no code or layout shared with the HIP
 library), written to tests/golden/full_size_counts.json.  The reference cannot run these sizes (its 500 MB
 per rank budget, reference: src/gpm-par.c:303-337, and days of run time); the counter is pinned to the
@@ -34,6 +34,25 @@ def main():
     dev = "cuda" if torch.cuda.is_available() else "cpu"
     result = {"made_by": "tests/golden/make_full_size_counts.py", "counter": "oracle/clique_count.c", "configs": {}}
     for cfg_id, cfg in sorted(bench.CONFIGS.items()):
+        if cfg["pattern"] == "tree5" and cfg["graph"]["graph"] == "plaw":
+            # the labelled tree: closed form over the arcs that carry the two centres' labels, numpy on the host
+            from tests.golden.tree_count import count_tree5
+            t0 = time.time()
+            graph = cfg["graph"]
+            n = graph["n"]
+            off, adj = gen.power_law(n, avg_deg=graph["avg_deg"], seed=graph["seed"], device=dev)
+            labels = gen.vertex_labels(n, cfg["labels"], seed=graph["seed"], device=dev).cpu().numpy()
+            o, a = off.cpu().numpy().astype(np.int64), adj.cpu().numpy().astype(np.int64)
+            del off, adj
+            print(f"config {cfg_id}: n={n} arcs={len(a)} generated in {time.time() - t0:.1f}s", flush=True)
+            t1 = time.time()
+            emb = count_tree5(n, o, a, labels, cfg["pattern_labels"])
+            got = {"embeddings": emb, "vertices": n, "arcs": int(len(a)), "seconds": round(time.time() - t1, 1),
+                   "counter": "tests/golden/tree_count.py",
+                   "workload": bench.describe(graph) + f", {cfg['labels']} labels, tree5 with labels {cfg['pattern_labels']}"}
+            print(f"config {cfg_id}: {got}", flush=True)
+            result["configs"][str(cfg_id)] = got
+            continue
         if cfg["pattern"] not in K or cfg.get("labels"):
             continue
         t0 = time.time()
