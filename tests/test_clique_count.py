@@ -24,6 +24,8 @@ def write_csr(path, n, off, adj):
 
 
 def count(path, k, threads=4):
+    if not os.path.exists(BIN):  # built with the rest of oracle/ (make -C oracle); here on demand
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all"], check=True, stdout=subprocess.DEVNULL)
     out = subprocess.run([BIN, path, str(k), str(threads)], check=True, capture_output=True, text=True).stdout
     return json.loads(out)
 
