@@ -50,19 +50,18 @@ CONFIGS = {
         "twin": {"graph": "rmat", "scale": 9, "ef": 8, "abcd": (0.7, 0.1, 0.1, 0.1), "seed": 1}},
 }
 
-# Embeddings of every configuration at full size.  No CPU program can enumerate them.  Configurations 1-4 are
-# pinned by independent counts on the CPU (tests/golden/full_size_counts.json): triangles, 4-cliques and
-# 4-cycles by oracle/clique_count.c, the labelled tree by the closed form of tests/golden/tree_count.py --
-# checkers that share nothing with the HIP library and are themselves pinned to the reference's vectors
-# (tests/test_clique_count.py, tests/test_tree_count.py).  Configuration 5's is what the independent device
-# paths agree on (fused levels against the level-by-level kernels), and the same kernels reproduce the
-# captured vectors of tests/golden at the sizes a CPU can reach.
+# Embeddings of every configuration at full size.  No CPU program can enumerate them.  All five are pinned by
+# independent counts on the CPU (tests/golden/full_size_counts.json): triangles, 4-cliques, 4-cycles and
+# octahedra (K6 minus a perfect matching) by oracle/clique_count.c, the labelled tree by the closed form of
+# tests/golden/tree_count.py -- checkers that share nothing with the HIP library and are themselves pinned to
+# the reference's vectors (tests/test_clique_count.py, tests/test_tree_count.py).
 EXPECTED_FULL = {1: 924, 2: 3614591580112, 3: 21123390052368, 4: 20278778911046, 5: 235455970772256}
 EXPECTED_FULL_SOURCE = {
     1: "independent CPU count (oracle/clique_count.c), tests/golden/full_size_counts.json",
     2: "independent CPU count (oracle/clique_count.c), tests/golden/full_size_counts.json",
     3: "independent CPU count (oracle/clique_count.c), tests/golden/full_size_counts.json",
     4: "independent closed-form count on the CPU (tests/golden/tree_count.py), tests/golden/full_size_counts.json",
+    5: "independent CPU count (oracle/clique_count.c), tests/golden/full_size_counts.json",
 }
 
 

@@ -1,4 +1,4 @@
-/* Independent count of triangles, 4-cliques and 4-cycles of a large simple undirected graph.
+/* Independent count of triangles, 4-cliques, 4-cycles and octahedra of a large simple undirected graph.
  *
  * TEST INFRASTRUCTURE, like the rest of oracle/: nothing on the product path may
  * link or run it.  It exists to pin the counts that the benchmark prints at sizes
@@ -25,9 +25,17 @@
  * 8 arcs has 8 automorphisms, so the reference finds each cycle 8 times.  Per root x one array of counters
  * indexed by y is filled by walking the lists of x's lower neighbours, summed and cleared the same way.
  *
+ * Octahedra ("oct": K6 minus a perfect matching, 12 edges, 48 automorphisms).  A copy has three pairs of
+ * opposite vertices; it is counted at the pair (u, u') that holds its lowest vertex u.  The other four
+ * vertices are higher neighbours of u that are also neighbours of u', and they form a 4-cycle: with
+ * T = N+(u) ^ N(u'), the copies at (u, u') are the 4-cycles of the subgraph T induces, i.e. half the sum
+ * over pairs {x, y} of T of c(c-1)/2, c = common neighbours of x and y inside T.  Per u the adjacency inside
+ * N+(u) is written down as bit rows and every u' above u gets a bit mask of the members of N+(u) it is
+ * adjacent to (filled by walking the lists of those members).
+ *
  * Input: a binary file  int64 n, int64 m, int64 off[n + 1], int32 adj[m]
  * (symmetric, no self loops, no duplicates, 0-based; list order is free).
- * usage: clique_count <file> <3 | 4 | c4> [threads]
+ * usage: clique_count <file> <3 | 4 | c4 | oct> [threads]
  */
 #include <inttypes.h>
 #include <pthread.h>
@@ -41,7 +49,8 @@ static int64_t *off;
 static int32_t *adj;
 static int64_t *poff;  /* N+ of every vertex: padj[poff[v] .. poff[v + 1]) */
 static int32_t *padj;
-static int kk, nthreads;
+static int kk, nthreads;  /* kk: 3, 4 = cliques, -4 = 4-cycles, -8 = octahedra */
+static int64_t max_plus;  /* longest N+ */
 static volatile int64_t next_root;
 static pthread_mutex_t lock = PTHREAD_MUTEX_INITIALIZER;
 static unsigned __int128 total;
@@ -62,10 +71,76 @@ static void *worker(void *arg) {
     uint64_t *rows = NULL;
     size_t rows_cap = 0;
     unsigned __int128 mine = 0;
+    /* octahedra: one mask of max_plus bits per vertex, the vertices whose mask is in use, a member list */
+    const size_t mw = (size_t)(max_plus + 63) / 64;
+    uint64_t *mask = NULL;
+    int32_t *touched = NULL, *members = NULL;
+    if (kk == -8) {
+        mask = calloc((size_t)n * mw + 1, sizeof(uint64_t));
+        touched = malloc((size_t)n * sizeof(int32_t));
+        members = malloc((size_t)(max_plus + 1) * sizeof(int32_t));
+        rows = malloc(((size_t)max_plus * mw + 1) * sizeof(uint64_t));
+        if (!mask || !touched || !members || !rows) {
+            fprintf(stderr, "clique_count: out of memory\n");
+            exit(1);
+        }
+    }
     for (;;) {
-        int64_t u0 = __sync_fetch_and_add(&next_root, 4096);
+        int64_t u0 = __sync_fetch_and_add(&next_root, kk == -8 ? 256 : 4096);
         if (u0 >= n) break;
-        int64_t u1 = u0 + 4096 < n ? u0 + 4096 : n;
+        int64_t u1 = u0 + (kk == -8 ? 256 : 4096) < n ? u0 + (kk == -8 ? 256 : 4096) : n;
+        for (int64_t u = u0; u < u1 && kk == -8; ++u) {
+            const int64_t b = poff[u], d = poff[u + 1] - b;
+            if (d < 4) continue;
+            for (int64_t i = 0; i < d; ++i) pos[padj[b + i]] = (int32_t)i;
+            memset(rows, 0, (size_t)d * mw * sizeof(uint64_t));
+            int64_t nt = 0;
+            for (int64_t i = 0; i < d; ++i) {
+                const int32_t x = padj[b + i];
+                for (int64_t p = off[x]; p < off[x + 1]; ++p) {
+                    const int32_t t = adj[p];
+                    const int32_t j = pos[t];
+                    if (j >= 0) rows[(size_t)i * mw + ((size_t)j >> 6)] |= 1ull << (j & 63); /* both directions */
+                    if (t == u || !lower((int32_t)u, t)) continue;
+                    uint64_t *mt = mask + (size_t)t * mw;
+                    int seen = 0;
+                    for (size_t y = 0; y < mw; ++y) seen |= mt[y] != 0;
+                    if (!seen) touched[nt++] = t;
+                    mt[(size_t)i >> 6] |= 1ull << (i & 63);
+                }
+            }
+            for (int64_t z = 0; z < nt; ++z) {
+                uint64_t *mt = mask + (size_t)touched[z] * mw;
+                int k = 0;
+                for (size_t y = 0; y < mw; ++y) {
+                    uint64_t bits = mt[y];
+                    while (bits) {
+                        members[k++] = (int32_t)(y * 64 + (size_t)__builtin_ctzll(bits));
+                        bits &= bits - 1;
+                    }
+                }
+                if (k >= 4) {
+                    uint64_t twice = 0; /* every 4-cycle of T is found at both of its diagonals */
+                    for (int p = 0; p < k; ++p)
+                        for (int q = p + 1; q < k; ++q) {
+                            const uint64_t *rp = rows + (size_t)members[p] * mw, *rq = rows + (size_t)members[q] * mw;
+                            uint64_t c = 0;
+                            for (size_t y = 0; y < mw; ++y) c += (uint64_t)__builtin_popcountll(rp[y] & rq[y] & mt[y]);
+                            twice += c * (c - (c ? 1 : 0)) / 2;
+                        }
+                    mine += twice / 2;
+                }
+                for (size_t y = 0; y < mw; ++y) mt[y] = 0;
+            }
+            for (int64_t i = 0; i < d; ++i) pos[padj[b + i]] = -1;
+        }
+        if (kk == -8) {
+            if ((u0 & ((1 << 16) - 1)) == 0) {
+                fprintf(stderr, "clique_count: roots from %" PRId64 " of %" PRId64 "\n", u0, n);
+                fflush(stderr);
+            }
+            continue;
+        }
         for (int64_t u = u0; u < u1 && kk == -4; ++u) {  /* 4-cycles: u is the highest vertex, pos[] counts */
             for (int64_t p = off[u]; p < off[u + 1]; ++p) {
                 const int32_t v = adj[p];
@@ -133,6 +208,9 @@ static void *worker(void *arg) {
     }
     free(rows);
     free(pos);
+    free(mask);
+    free(touched);
+    free(members);
     pthread_mutex_lock(&lock);
     total += mine;
     pthread_mutex_unlock(&lock);
@@ -152,13 +230,13 @@ static void print_u128(unsigned __int128 v) {
 
 int main(int argc, char **argv) {
     if (argc < 3) {
-        fprintf(stderr, "usage: clique_count <csr file> <3|4|c4> [threads]\n");
+        fprintf(stderr, "usage: clique_count <csr file> <3|4|c4|oct> [threads]\n");
         return 2;
     }
-    kk = strcmp(argv[2], "c4") == 0 ? -4 : atoi(argv[2]);
+    kk = strcmp(argv[2], "c4") == 0 ? -4 : strcmp(argv[2], "oct") == 0 ? -8 : atoi(argv[2]);
     nthreads = argc > 3 ? atoi(argv[3]) : 8;
-    if ((kk != 3 && kk != 4 && kk != -4) || nthreads < 1 || nthreads > 256) {
-        fprintf(stderr, "clique_count: pattern must be 3, 4 or c4, threads 1..256\n");
+    if ((kk != 3 && kk != 4 && kk != -4 && kk != -8) || nthreads < 1 || nthreads > 256) {
+        fprintf(stderr, "clique_count: pattern must be 3, 4, c4 or oct, threads 1..256\n");
         return 2;
     }
     FILE *f = fopen(argv[1], "rb");
@@ -187,13 +265,16 @@ int main(int argc, char **argv) {
         for (int64_t p = off[v]; p < off[v + 1]; ++p)
             if (lower((int32_t)v, adj[p])) padj[at++] = adj[p];
     }
+    for (int64_t v = 0; v < n; ++v)
+        if (poff[v + 1] - poff[v] > max_plus) max_plus = poff[v + 1] - poff[v];
     pthread_t th[256];
     for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, worker, NULL);
     for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
     unsigned __int128 emb = total;
     for (int i = 2; i <= kk; ++i) emb *= (unsigned)i;
     if (kk == -4) emb = total * 8;
-    printf("{\"k\": %d, \"%s\": ", kk == -4 ? 4 : kk, kk == -4 ? "cycles" : "cliques");
+    if (kk == -8) emb = total * 48;
+    printf("{\"k\": %d, \"%s\": ", kk == -4 ? 4 : kk == -8 ? 6 : kk, kk == -4 ? "cycles" : kk == -8 ? "octahedra" : "cliques");
     print_u128(total);
     printf(", \"embeddings\": ");
     print_u128(emb);

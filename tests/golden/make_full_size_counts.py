@@ -25,7 +25,7 @@ from mpi_amd import gen  # noqa: E402
 import bench  # noqa: E402
 
 BIN = os.path.join(ROOT, "oracle", "_build", "clique_count")
-K = {"triangle": "3", "clique4": "4", "cycle4": "c4"}
+K = {"triangle": "3", "clique4": "4", "cycle4": "c4", "k6_minus_pm": "oct"}
 
 
 def main():

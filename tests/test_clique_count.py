@@ -1,6 +1,6 @@
 """The independent counter of cliques and 4-cycles (oracle/clique_count.c) against the vectors captured from
-the compiled reference: it is what pins the benchmark's counts at sizes the reference cannot reach, so it is
-itself pinned to every triangle / 4-clique / 4-cycle vector the reference did produce."""
+the compiled reference (octahedron = K6 minus a perfect matching): it is what pins the benchmark's counts at sizes the reference cannot reach, so it is
+itself pinned to every triangle / 4-clique / 4-cycle / octahedron vector the reference did produce."""
 import json
 import os
 import subprocess
@@ -13,7 +13,7 @@ from tests import util
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_build", "clique_count")
-K = {"triangle": "3", "clique4": "4", "cycle4": "c4"}
+K = {"triangle": "3", "clique4": "4", "cycle4": "c4", "k6_minus_pm": "oct"}
 
 
 def write_csr(path, n, off, adj):
@@ -66,6 +66,7 @@ def test_counter_on_a_complete_graph(tmp_path):
     assert count(path, 3)["embeddings"] == n * (n - 1) * (n - 2)
     assert count(path, 4)["embeddings"] == n * (n - 1) * (n - 2) * (n - 3)
     assert count(path, "c4")["embeddings"] == n * (n - 1) * (n - 2) * (n - 3)  # every injective map of 4 vertices
+    assert count(path, "oct")["embeddings"] == n * (n - 1) * (n - 2) * (n - 3) * (n - 4) * (n - 5)
 
 
 def test_benchmark_counts_come_from_the_independent_counter():
@@ -74,5 +75,6 @@ def test_benchmark_counts_come_from_the_independent_counter():
     import bench
     with open(os.path.join(ROOT, "tests", "golden", "full_size_counts.json")) as f:
         full = json.load(f)
+    assert sorted(full["configs"]) == ["1", "2", "3", "4", "5"]
     for cfg, entry in full["configs"].items():
         assert bench.EXPECTED_FULL[int(cfg)] == entry["embeddings"], cfg
