@@ -113,7 +113,8 @@ enum {
     GPM_KIND_CLIQUE = 2,    /* cliques, small universes: bitmap rows built and counted in LDS */
     GPM_KIND_CLQ_BUILD = 3, /* cliques, large universes: bitmap rows built into HBM */
     GPM_KIND_CLQ_COUNT = 4, /* cliques, large universes: rows counted from LDS tiles */
-    GPM_KIND_CYCLE4 = 5     /* 4-cycles: two-path counters */
+    GPM_KIND_CYCLE4 = 5,    /* 4-cycles: two-path counters */
+    GPM_KIND_OCTA = 6       /* octahedra (K6 minus a perfect matching): 4-cycles among common higher neighbours */
 };
 
 typedef struct {

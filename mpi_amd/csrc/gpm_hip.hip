@@ -109,7 +109,7 @@ struct EventPair {
 };
 
 static const char *const kKindNames[GPM_KERNEL_KINDS] = {"k_tail", "k_extend", "k_clique", "k_clq_build",
-                                                         "k_clq_count4", "k_cycle4", "", ""};
+                                                         "k_clq_count4", "k_cycle4", "k_octa", ""};
 
 // One chunk of the root range; in clique mode also its roots per size class.
 struct Chunk {
@@ -197,6 +197,11 @@ struct DevState {
     uint64_t cyc_single_ver = 0;
     LeafTerm *ls_terms = nullptr;  // inclusion-exclusion terms of the leaf-suffix kernel
     unsigned long long *cyc_queue = nullptr;
+    // octahedron path: per-workgroup slabs of masks ((octa_w + 1) words per vertex) and touched lists, root queues
+    uint32_t *octa_mask = nullptr;
+    int32_t *octa_touched = nullptr;
+    unsigned long long *octa_queue = nullptr;
+    int octa_wgs = 0, octa_w = 0;  // octa_wgs = -1: the graph does not fit the kernel (longest N+, memory)
     std::vector<EventPair> events;
     size_t events_used = 0;
     // results of the last search
@@ -232,6 +237,8 @@ struct gpm_ctx {
     bool use_clique = true;
     bool cycle4 = false;  // the plan is the 4-cycle with all 8 automorphisms folded
     bool use_cycle4 = true;
+    bool octa = false;    // the plan is K6 minus a perfect matching with all 48 automorphisms folded
+    bool use_octa = true;
     bool accounting = true;  // sum merge-model bytes in the clique kernels (gpm_hip_set_accounting)
     // tuning knobs, read from the environment once when the context is made
     int64_t fuse3_group = 8, twin_group = 1;
@@ -419,6 +426,13 @@ static void free_graph(DevState &d) {
     dev_free(d.cyc_single);
     d.cyc_single = nullptr;
     d.cyc_single_ver = 0;
+    dev_free(d.octa_mask);
+    dev_free(d.octa_touched);
+    dev_free(d.octa_queue);
+    d.octa_mask = nullptr;
+    d.octa_touched = nullptr;
+    d.octa_queue = nullptr;
+    d.octa_wgs = d.octa_w = 0;
     d.cyc_cost = nullptr;
     d.cyc_dense = nullptr;
     d.cyc_queue = nullptr;
@@ -551,6 +565,7 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->use_tail = env_i64("GPM_NO_TAIL", 0) == 0;
     ctx->use_clique = env_i64("GPM_NO_CLIQUE", 0) == 0;
     ctx->use_cycle4 = env_i64("GPM_NO_CYCLE4", 0) == 0;
+    ctx->use_octa = env_i64("GPM_NO_OCTA", 0) == 0;
     ctx->cyc_rule.heavy_from = std::max<int64_t>(1, env_i64("GPM_CYCLE4_HEAVY", (int64_t)1 << 16));
     ctx->accounting = env_i64("GPM_ACCOUNTING", 1) != 0;
     {
@@ -1218,6 +1233,21 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
             for (int j = 0; j < lv.n_cons; ++j) deg[lv.cons_level[j]]++, deg[k]++, edges++;
         }
         ctx->cycle4 = plain && edges == 4 && deg[0] == 2 && deg[1] == 2 && deg[2] == 2 && deg[3] == 2;
+    }
+    // K6 minus a perfect matching (the octahedron) with its 48 automorphisms folded, no labels: twelve pattern
+    // edges, every vertex on four of them (the only 4-regular graph on six vertices).
+    ctx->octa = false;
+    if (P == 6 && ctx->info.simple && ctx->info.symmetric && p->n_aut == 48) {
+        int deg[6] = {0, 0, 0, 0, 0, 0}, edges = 0;
+        bool plain = pv.lv[0].label < 0;
+        for (int k = 1; k < P; ++k) {
+            const LevelPlan &lv = pv.lv[k];
+            plain = plain && lv.label < 0;
+            deg[lv.src_level]++, deg[k]++, edges++;
+            for (int j = 0; j < lv.n_cons; ++j) deg[lv.cons_level[j]]++, deg[k]++, edges++;
+        }
+        ctx->octa = plain && edges == 12;
+        for (int k = 0; k < P; ++k) ctx->octa = ctx->octa && deg[k] == 4;
     }
     ctx->have_plan = true;
     return GPM_OK;
@@ -2152,6 +2182,48 @@ static int ensure_cycle4(gpm_ctx *ctx, DevState &d) {
     return GPM_OK;
 }
 
+// Buffers of the octahedron path on one device, sized for the graph: the kernel needs the longest N+ to fit
+// its LDS rows and (longest N+ / 32 + 1) words per vertex and workgroup for the masks.  octa_wgs = -1 when
+// the graph does not fit (the search then takes the general kernels).
+static int ensure_octa(gpm_ctx *ctx, DevState &d) {
+    if (d.octa_wgs) return GPM_OK;
+    HIP_TRY(hipSetDevice(d.dev));
+    hipStream_t s = d.stream;
+    const int64_t n = ctx->info.n;
+    Scratch mx;
+    HIP_TRY(mx.alloc(sizeof(int)));
+    HIP_TRY(hipMemsetAsync(mx.p, 0, sizeof(int), s));
+    if (n > 0) k_max_plus<<<grid_for(n), 256, 0, s>>>(d.gv, mx.as<int>());
+    HIP_TRY(hipGetLastError());
+    int max_plus = 0;
+    HIP_TRY(hipMemcpyAsync(&max_plus, mx.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    d.octa_wgs = -1;
+    if (max_plus > OCTA_MAX_D) return GPM_OK;
+    const int W = std::max(1, (max_plus + 31) / 32);
+    const int64_t budget = env_i64("GPM_OCTA_MEM_GB", 16) << 30;
+    const int64_t per_wg = n * (int64_t)(W + 2) * 4;
+    const int64_t wgs = std::min<int64_t>(env_i64("GPM_OCTA_BLOCKS", 1024), per_wg > 0 ? budget / per_wg : 0);
+    if (wgs < 64) return GPM_OK;
+    const size_t mask_bytes = (size_t)wgs * (size_t)n * (size_t)(W + 1) * sizeof(uint32_t);
+    if (hipMalloc(&d.octa_mask, mask_bytes) != hipSuccess || hipMalloc(&d.octa_touched, (size_t)wgs * (size_t)n * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&d.octa_queue, 1024 * sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipGetLastError();
+        dev_free(d.octa_mask);
+        dev_free(d.octa_touched);
+        dev_free(d.octa_queue);
+        d.octa_mask = nullptr;
+        d.octa_touched = nullptr;
+        d.octa_queue = nullptr;
+        return GPM_OK;
+    }
+    HIP_TRY(hipMemsetAsync(d.octa_mask, 0, mask_bytes, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    d.octa_w = W;
+    d.octa_wgs = (int)wgs;
+    return GPM_OK;
+}
+
 // Cut the root range into chunks of similar estimated cost (heaviest roots
 // first, so early chunks are short), capped at chunk_roots roots each.  Every
 // context over the same graph, plan, root range and hint builds the same table,
@@ -2224,7 +2296,7 @@ static int prepare_chunks(gpm_ctx *ctx) {
         }
     int64_t want = ctx->chunk_hint > 0 ? ctx->chunk_hint : 32 * (int64_t)ctx->devs.size();
     // the two-path counts are exact costs and every chunk is one persistent launch: few, large chunks
-    if (cyc) want = std::max<int64_t>(1, want / 8);
+    if (cyc || (ctx->octa && ctx->use_octa)) want = std::max<int64_t>(1, want / 8);
     // the level-by-level path synchronises with the host several times per chunk: fewer, larger chunks
     else if (!(ctx->clique_k && ctx->use_clique)) want = std::max<int64_t>(1, want / 8);
     const int64_t target = std::max<int64_t>(1, hpref.back() / want);
@@ -2297,6 +2369,15 @@ static int device_search(const SearchArgs &a, DevState &d) {
     const bool clique = a.count_only && ctx->clique_k >= 3 && ctx->use_clique && !a.fixed_memory;
     if (clique) HIP_TRY(hipMemsetAsync(d.clq_slots, 0, GPM_KERNEL_KINDS * CLQ_SLOTS * sizeof(unsigned long long), s));
     HIP_TRY(hipStreamSynchronize(s));  // counters are zero before any slot stream adds to them
+    bool octa = a.count_only && ctx->octa && ctx->use_octa && !a.fixed_memory;
+    if (octa) {
+        if ((rc = ensure_octa(ctx, d))) return rc;
+        octa = d.octa_wgs > 0;
+        if (octa) {
+            HIP_TRY(hipMemsetAsync(d.octa_queue, 0, 1024 * sizeof(unsigned long long), s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+    }
     const bool cyc = a.count_only && ctx->cycle4 && ctx->use_cycle4 && !a.fixed_memory;
     if (cyc) {
         if ((rc = ensure_cycle4(ctx, d))) return rc;
@@ -2334,6 +2415,26 @@ static int device_search(const SearchArgs &a, DevState &d) {
         const Chunk &ch = a.fixed_memory ? fixed_chunk : ctx->chunks[(size_t)c];
         const int64_t lo = ch.lo, hi = ch.hi;
         d.chunks++;
+        if (octa) {
+            // one launch per chunk on the main stream: the workgroups take the chunk's roots from a queue
+            // and share nothing but that; launches follow each other (the slabs belong to workgroup numbers)
+            if (seq && seq % 1024 == 0) {
+                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(hipMemsetAsync(d.octa_queue, 0, 1024 * sizeof(unsigned long long), s));
+            }
+            d.rows_in[0] += (uint64_t)(hi - lo);
+            if ((rc = timed_begin(d, GPM_KIND_OCTA, hi - lo, s))) return rc;
+            k_octa<<<(unsigned)d.octa_wgs, 256, OCTA_LDS_BYTES(d.octa_w), s>>>(d.gv, lo, hi, d.octa_queue + seq % 1024, d.octa_mask,
+                                                                              d.octa_touched, d.octa_w, d.ctr + CTR_TAIL_MATCHES);
+            HIP_TRY(hipGetLastError());
+            if ((rc = timed_end(d, s))) return rc;
+            seq++;
+            if (d.events_used > 4096) {
+                HIP_TRY(hipStreamSynchronize(s));
+                if ((rc = collect_times(d, ctx->trace))) return rc;
+            }
+            continue;
+        }
         if (cyc) {
             // light roots of the chunk: one launch on the first slot stream (launches share the
             // workgroups' counter arrays, so they run one after the other); heavy roots: one launch

@@ -2642,6 +2642,135 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
 }
 
 // ---------------------------------------------------------------------------
+// Octahedra (K6 minus a perfect matching): 4-cycles among the common higher
+// neighbours of a pair of opposite vertices
+// ---------------------------------------------------------------------------
+//
+// The pattern's six vertices form three pairs of opposite (non-adjacent) vertices, every other pair is
+// adjacent.  A copy is counted at the pair (u, u') that holds its lowest vertex u (ids are degree ranks): its
+// other four vertices are higher neighbours of u that are neighbours of u' as well, and they form a
+// 4-cycle.  With U = N+(u) and T = U ^ N(u'), the copies at (u, u') are the 4-cycles of the subgraph T
+// induces: half the sum over pairs {x, y} of T of c(c-1)/2, c = |N(x) ^ N(y) ^ T|.  Each copy stands for 48
+// embeddings (the reference reports every automorphic image, reference: src/gpm-par.c:179-243).
+//
+// One workgroup per root u, roots taken from a queue.  Every vertex t above u gets a bit mask over the
+// positions of U: the members of U adjacent to t.  The masks live in a slab of global memory that belongs
+// to the workgroup ((W + 1) words per vertex of the graph, all zero between roots): the waves walk the lists
+// of U's members above u and OR the member's bit into the mask of every entry (atomics in L2; word W of a
+// mask is a flag whose first setter appends the vertex to the workgroup's list of touched vertices).  The
+// masks of U's own members are the adjacency inside U, both directions: they are copied to LDS as rows.  Then
+// every touched vertex t with at least four bits is a u': a wave lists the members of its mask and its lanes
+// take the pairs {x, y}, three-way AND of two LDS rows and the mask.  Masks are cleared as they are used.
+// Universes of up to OCTA_MAX_D vertices; the caller checks the longest N+ and the memory for the slabs.
+// Dynamic LDS (words): U[OCTA_MAX_D] | rows[OCTA_MAX_D * W] | per wave: members[OCTA_MAX_D / 2] (16-bit) | mask[W].
+#define OCTA_MAX_D 512
+#define OCTA_LDS_BYTES(W) ((OCTA_MAX_D + OCTA_MAX_D * (W) + 4 * (OCTA_MAX_D / 2 + (W))) * 4)
+
+__global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t hi, unsigned long long *queue,
+                                              uint32_t *mask_all, int32_t *touched_all, int W,
+                                              unsigned long long *n_copies) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ long long s_root;
+    __shared__ int s_nt;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
+    int32_t *U = (int32_t *)smem;
+    uint32_t *rows = smem + OCTA_MAX_D;
+    uint16_t *members = (uint16_t *)(smem + OCTA_MAX_D + OCTA_MAX_D * W + wave * (OCTA_MAX_D / 2 + W));
+    uint32_t *wmask = smem + OCTA_MAX_D + OCTA_MAX_D * W + wave * (OCTA_MAX_D / 2 + W) + OCTA_MAX_D / 2;
+    const int stride = W + 1;
+    uint32_t *mask = mask_all + (size_t)blockIdx.x * (size_t)g.n * (size_t)stride;
+    int32_t *touched = touched_all + (size_t)blockIdx.x * (size_t)g.n;
+    const int64_t *off = g.off[0], *mid = g.mid[0];
+    const int32_t *adj = g.adj[0];
+    uint64_t acc = 0;
+    for (;;) {
+        __syncthreads();  // the last root is done with s_root, s_nt and the LDS rows
+        if (tid == 0) {
+            s_root = (long long)(lo + (int64_t)atomicAdd(queue, 1ull));
+            s_nt = 0;
+        }
+        __syncthreads();
+        const int64_t ri = s_root;
+        if (ri >= hi) break;
+        const int32_t u = (int32_t)(g.n - 1 - ri);
+        const int64_t ub = mid[u];
+        const int d = (int)(off[u + 1] - ub);
+        if (d < 4) continue;
+        for (int x = tid; x < d; x += 256) U[x] = adj[ub + x];
+        __syncthreads();
+        // masks: member x sets its bit in the mask of every neighbour above u (lists ascend: entered above u)
+        for (int x = wave; x < d; x += 4) {
+            const int32_t mvert = U[x];
+            const int64_t e = off[mvert + 1];
+            const int64_t b = lower_bound_g(adj, off[mvert], e, u + 1);
+            const uint32_t bit = 1u << (x & 31);
+            for (int64_t p = b + lane; p < e; p += GPM_WAVE) {
+                const int32_t t = adj[p];
+                uint32_t *mt = mask + (size_t)t * (size_t)stride;
+                if (atomicOr(mt + (x >> 5), bit) == 0u && atomicOr(mt + W, 1u) == 0u) touched[atomicAdd(&s_nt, 1)] = t;
+            }
+        }
+        __syncthreads();
+        const int nt = s_nt;
+        // the masks of U's members are the adjacency inside U (read past the L1: they were written by atomics)
+        for (int x = tid; x < d * W; x += 256) {
+            const int i = x / W, w = x - i * W;
+            rows[x] = __hip_atomic_load(mask + (size_t)U[i] * (size_t)stride + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        for (int z = wave; z < nt; z += 4) {
+            const int32_t t = __hip_atomic_load(touched + z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t *mt = mask + (size_t)t * (size_t)stride;
+            uint32_t mine = 0;
+            if (lane < W) mine = __hip_atomic_load(mt + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < W && mine) atomicExch(mt + lane, 0u);  // cleared for the next root
+            if (lane == W) atomicExch(mt + W, 0u);
+            int k = __popc(mine);
+            for (int o = 32; o > 0; o >>= 1) k += __shfl_xor(k, o, GPM_WAVE);
+            if (k < 4) continue;
+            wave_lds_sync();
+            if (lane < W) wmask[lane] = mine;
+            {  // positions of the mask's bits, in ascending order: lane l lists the bits of word l
+                int before = __popc(mine);
+                int incl = before;
+                for (int o = 1; o < GPM_WAVE; o <<= 1) {
+                    const int up = __shfl_up(incl, o, GPM_WAVE);
+                    if (lane >= o) incl += up;
+                }
+                int at = incl - before;
+                uint32_t bits = mine;
+                while (bits) {
+                    members[at++] = (uint16_t)(32 * lane + __builtin_ctz(bits));
+                    bits &= bits - 1;
+                }
+            }
+            wave_lds_sync();
+            uint64_t twice = 0;  // every 4-cycle of T is found at both of its diagonals
+            for (int p = 0; p + 1 < k; ++p) {
+                const uint32_t *rp = rows + (int)members[p] * W;
+                for (int q = p + 1 + lane; q < k; q += GPM_WAVE) {
+                    const uint32_t *rq = rows + (int)members[q] * W;
+                    uint32_t c = 0;
+                    for (int w = 0; w < W; ++w) c += __popc(rp[w] & rq[w] & wmask[w]);
+                    twice += (uint64_t)c * (c - (c ? 1u : 0u)) / 2;
+                }
+            }
+            twice = wave_sum_u64(twice);
+            if (lane == 0) acc += twice / 2;
+        }
+    }
+    if (lane == 0 && acc) atomicAdd(n_copies, (unsigned long long)acc);
+}
+
+// Longest N+ of the graph (the universes of the clique and octahedron kernels).
+__global__ void k_max_plus(GraphView g, int *out) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int d = v < g.n ? (int)(g.off[0][v + 1] - g.mid[0][v]) : 0;
+    for (int o = 32; o > 0; o >>= 1) d = max(d, __shfl_xor(d, o, GPM_WAVE));
+    if (lane_id() == 0 && d > 0) atomicMax(out, d);
+}
+
+// ---------------------------------------------------------------------------
 // Output: matches as text lines, formatted on the GPU
 // ---------------------------------------------------------------------------
 //
