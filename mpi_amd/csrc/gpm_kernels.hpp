@@ -2657,14 +2657,16 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
 // positions of U: the members of U adjacent to t.  The masks live in a slab of global memory that belongs
 // to the workgroup ((W + 1) words per vertex of the graph, all zero between roots): the waves walk the lists
 // of U's members above u and OR the member's bit into the mask of every entry (atomics in L2; word W of a
-// mask is a flag whose first setter appends the vertex to the workgroup's list of touched vertices).  The
+// mask says which of its words hold bits, and who finds it empty appends the vertex to the workgroup's list
+// of touched vertices).  The
 // masks of U's own members are the adjacency inside U, both directions: they are copied to LDS as rows.  Then
 // every touched vertex t with at least four bits is a u': a wave lists the members of its mask and its lanes
 // take the pairs {x, y}, three-way AND of two LDS rows and the mask.  Masks are cleared as they are used.
 // Universes of up to OCTA_MAX_D vertices; the caller checks the longest N+ and the memory for the slabs.
-// Dynamic LDS (words): U[OCTA_MAX_D] | rows[OCTA_MAX_D * W] | per wave: members[OCTA_MAX_D / 2] (16-bit) | mask[W].
+// Dynamic LDS (words), Wr = W rounded up to 4: U[OCTA_MAX_D] | rows[OCTA_MAX_D * Wr] | per wave: members[OCTA_MAX_D / 2] (16-bit) | mask[Wr].
 #define OCTA_MAX_D 512
-#define OCTA_LDS_BYTES(W) ((OCTA_MAX_D + OCTA_MAX_D * (W) + 4 * (OCTA_MAX_D / 2 + (W))) * 4)
+#define OCTA_ROW_WORDS(W) (((W) + 3) & ~3)  // rows and the wave's mask copy are read 16 bytes at a time
+#define OCTA_LDS_BYTES(W) ((OCTA_MAX_D + OCTA_MAX_D * OCTA_ROW_WORDS(W) + 4 * (OCTA_MAX_D / 2 + OCTA_ROW_WORDS(W))) * 4)
 
 __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t hi, unsigned long long *queue,
                                               uint32_t *mask_all, int32_t *touched_all, int W,
@@ -2675,8 +2677,9 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
     int32_t *U = (int32_t *)smem;
     uint32_t *rows = smem + OCTA_MAX_D;
-    uint16_t *members = (uint16_t *)(smem + OCTA_MAX_D + OCTA_MAX_D * W + wave * (OCTA_MAX_D / 2 + W));
-    uint32_t *wmask = smem + OCTA_MAX_D + OCTA_MAX_D * W + wave * (OCTA_MAX_D / 2 + W) + OCTA_MAX_D / 2;
+    const int Wr = OCTA_ROW_WORDS(W), Wq = Wr / 4;
+    uint16_t *members = (uint16_t *)(smem + OCTA_MAX_D + OCTA_MAX_D * Wr + wave * (OCTA_MAX_D / 2 + Wr));
+    uint32_t *wmask = smem + OCTA_MAX_D + OCTA_MAX_D * Wr + wave * (OCTA_MAX_D / 2 + Wr) + OCTA_MAX_D / 2;
     const int stride = W + 1;
     uint32_t *mask = mask_all + (size_t)blockIdx.x * (size_t)g.n * (size_t)stride;
     int32_t *touched = touched_all + (size_t)blockIdx.x * (size_t)g.n;
@@ -2707,56 +2710,97 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
             for (int64_t p = b + lane; p < e; p += GPM_WAVE) {
                 const int32_t t = adj[p];
                 uint32_t *mt = mask + (size_t)t * (size_t)stride;
-                if (atomicOr(mt + (x >> 5), bit) == 0u && atomicOr(mt + W, 1u) == 0u) touched[atomicAdd(&s_nt, 1)] = t;
+                // word W of a mask says which of its words hold bits; who finds it empty lists the vertex
+                if (atomicOr(mt + (x >> 5), bit) == 0u && atomicOr(mt + W, 1u << (x >> 5)) == 0u) touched[atomicAdd(&s_nt, 1)] = t;
             }
         }
         __syncthreads();
         const int nt = s_nt;
         // the masks of U's members are the adjacency inside U (read past the L1: they were written by atomics)
-        for (int x = tid; x < d * W; x += 256) {
-            const int i = x / W, w = x - i * W;
-            rows[x] = __hip_atomic_load(mask + (size_t)U[i] * (size_t)stride + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int x = tid; x < d * Wr; x += 256) {
+            const int i = x / Wr, w = x - i * Wr;
+            rows[x] = w < W ? __hip_atomic_load(mask + (size_t)U[i] * (size_t)stride + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         }
         __syncthreads();
-        for (int z = wave; z < nt; z += 4) {
-            const int32_t t = __hip_atomic_load(touched + z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t *mt = mask + (size_t)t * (size_t)stride;
-            uint32_t mine = 0;
-            if (lane < W) mine = __hip_atomic_load(mt + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane < W && mine) atomicExch(mt + lane, 0u);  // cleared for the next root
-            if (lane == W) atomicExch(mt + W, 0u);
-            int k = __popc(mine);
-            for (int o = 32; o > 0; o >>= 1) k += __shfl_xor(k, o, GPM_WAVE);
-            if (k < 4) continue;
-            wave_lds_sync();
-            if (lane < W) wmask[lane] = mine;
-            {  // positions of the mask's bits, in ascending order: lane l lists the bits of word l
-                int before = __popc(mine);
-                int incl = before;
-                for (int o = 1; o < GPM_WAVE; o <<= 1) {
-                    const int up = __shfl_up(incl, o, GPM_WAVE);
-                    if (lane >= o) incl += up;
+        // Most touched vertices are adjacent to fewer than four members.  A wave therefore takes 64 touched
+        // vertices at a time, one per lane: every lane reads and clears the mask of its vertex (the reads of
+        // 64 masks are in flight together) and counts its bits; the vertices with at least four bits are then
+        // taken one after the other by the whole wave.
+        for (int z0 = wave * GPM_WAVE; z0 < nt; z0 += 4 * GPM_WAVE) {
+            const int z = z0 + lane;
+            uint32_t mw[OCTA_MAX_D / 32];
+            int k = 0;
+            if (z < nt) {
+                const int32_t t = __hip_atomic_load(touched + z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t *mt = mask + (size_t)t * (size_t)stride;
+                // only the words that hold bits are read (one, for most vertices)
+                const uint32_t filled = __hip_atomic_load(mt + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int w = 0; w < OCTA_MAX_D / 32; ++w)
+                    mw[w] = (filled >> w) & 1u ? __hip_atomic_load(mt + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+                for (int w = 0; w < OCTA_MAX_D / 32; ++w) {
+                    k += __popc(mw[w]);
+                    if (mw[w]) atomicExch(mt + w, 0u);  // cleared for the next root
                 }
-                int at = incl - before;
-                uint32_t bits = mine;
-                while (bits) {
-                    members[at++] = (uint16_t)(32 * lane + __builtin_ctz(bits));
-                    bits &= bits - 1;
-                }
+                atomicExch(mt + W, 0u);
+            } else {
+#pragma unroll
+                for (int w = 0; w < OCTA_MAX_D / 32; ++w) mw[w] = 0;
             }
-            wave_lds_sync();
-            uint64_t twice = 0;  // every 4-cycle of T is found at both of its diagonals
-            for (int p = 0; p + 1 < k; ++p) {
-                const uint32_t *rp = rows + (int)members[p] * W;
-                for (int q = p + 1 + lane; q < k; q += GPM_WAVE) {
-                    const uint32_t *rq = rows + (int)members[q] * W;
+            unsigned long long big = __ballot(k >= 4);
+            while (big) {
+                const int src = __builtin_ctzll(big);
+                big &= big - 1;
+                wave_lds_sync();
+                if (lane == src) {
+#pragma unroll
+                    for (int w = 0; w < OCTA_MAX_D / 32; ++w)
+                        if (w < Wr) wmask[w] = mw[w];  // words from W on are zeros
+                }
+                wave_lds_sync();
+                const uint32_t mine = lane < W ? wmask[lane] : 0u;
+                const int kk = __builtin_amdgcn_readlane(k, src);
+                {  // positions of the mask's bits, in ascending order: lane l lists the bits of word l
+                    const int before = __popc(mine);
+                    int incl = before;
+                    for (int o = 1; o < GPM_WAVE; o <<= 1) {
+                        const int up = __shfl_up(incl, o, GPM_WAVE);
+                        if (lane >= o) incl += up;
+                    }
+                    int at = incl - before;
+                    uint32_t bits = mine;
+                    while (bits) {
+                        members[at++] = (uint16_t)(32 * lane + __builtin_ctz(bits));
+                        bits &= bits - 1;
+                    }
+                }
+                wave_lds_sync();
+                uint64_t twice = 0;  // every 4-cycle of T is found at both of its diagonals
+                // The kk (kk - 1) / 2 pairs are dealt out to the lanes as one sequence (row p holds the pairs
+                // (p, p + 1) .. (p, kk - 1)): most sets are small, and a lane per pair of one row at a time
+                // would leave most lanes idle.  A lane keeps its place as (p, r) = r-th pair of row p.
+                int pp = 0, r = lane;
+                while (pp < kk - 1 && r >= kk - 1 - pp) {
+                    r -= kk - 1 - pp;
+                    ++pp;
+                }
+                while (pp < kk - 1) {
+                    const uint32_t *rp = rows + (int)members[pp] * Wr, *rq = rows + (int)members[pp + 1 + r] * Wr;
                     uint32_t c = 0;
-                    for (int w = 0; w < W; ++w) c += __popc(rp[w] & rq[w] & wmask[w]);
+#pragma unroll
+                    for (int v = 0; v < OCTA_MAX_D / 128; ++v)
+                        if (v < Wq) c = and_popc_add4(and4(load4(rp + 4 * v), load4(wmask + 4 * v)), load4(rq + 4 * v), c);
                     twice += (uint64_t)c * (c - (c ? 1u : 0u)) / 2;
+                    r += GPM_WAVE;
+                    while (pp < kk - 1 && r >= kk - 1 - pp) {
+                        r -= kk - 1 - pp;
+                        ++pp;
+                    }
                 }
+                twice = wave_sum_u64(twice);
+                if (lane == 0) acc += twice / 2;
             }
-            twice = wave_sum_u64(twice);
-            if (lane == 0) acc += twice / 2;
         }
     }
     if (lane == 0 && acc) atomicAdd(n_copies, (unsigned long long)acc);
