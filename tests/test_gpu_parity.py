@@ -117,7 +117,7 @@ def test_golden_counts_and_multisets(spec):
 
 
 LARGE = util.golden_large_specs()
-KIND_CLQ_BUILD, KIND_CLQ_COUNT, KIND_CYCLE4 = 3, 4, 5  # GPM_KIND_* of include/gpm_hip.h
+KIND_CLQ_BUILD, KIND_CLQ_COUNT, KIND_CYCLE4, KIND_OCTA = 3, 4, 5, 6  # GPM_KIND_* of include/gpm_hip.h
 # device paths a large vector is run through: (environment, accounting on, kernel families that must have run)
 LARGE_PATHS = {
     "clique4": [({}, True, ()), ({}, False, ()),
@@ -138,6 +138,9 @@ LARGE_PATHS = {
                  ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_KAPPA4": "-1"}, False, (KIND_CLQ_BUILD,)),
                  ({"GPM_CLIQUE_SMALL_MAX": "24", "GPM_CLQ_KAPPA4": "0"}, False, (KIND_CLQ_BUILD,)),
                  ({"GPM_CLIQUE_SMALL_MAX": "24"}, False, (KIND_CLQ_BUILD,))],
+    # octahedra counted at the lowest vertex of a copy (masks over N+(u), few and many workgroups), and the
+    # general kernels (fused three-level tail)
+    "k6_minus_pm": [({}, True, (KIND_OCTA,)), ({"GPM_OCTA_BLOCKS": "64"}, True, (KIND_OCTA,)), ({"GPM_NO_OCTA": "1"}, True, ())],
     # heavy roots as spans of two-paths on counter arrays in global memory; the heaviest with their counters
     # in LDS, one workgroup per range of ids (dozens of narrow ranges) and, with several arc blocks per root,
     # the blocks' counts merged through the root's array in global memory
@@ -160,7 +163,7 @@ def test_large_goldens(spec, monkeypatch):
     for env, accounting, kinds in LARGE_PATHS.get(spec["pattern"], [({}, True, ())]):
         for k in ("GPM_CLIQUE_SMALL_MAX", "GPM_CLQ_LISTS_MAX_CLASS", "GPM_COUNT4_WAVES", "GPM_CYCLE4_HEAVY", "GPM_CLQ_KAPPA4",
                   "GPM_CLQ_LISTS_WAVES", "GPM_CLIQUE_TINY", "GPM_CYC_RANGE_IDS", "GPM_CYC_RANGES",
-                  "GPM_CYC_RANGES_FROM", "GPM_CYC_RANGE_TILES", "GPM_CYC_RANGE_WORK"):
+                  "GPM_CYC_RANGES_FROM", "GPM_CYC_RANGE_TILES", "GPM_CYC_RANGE_WORK", "GPM_OCTA_BLOCKS", "GPM_NO_OCTA"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -871,3 +874,27 @@ def test_the_cost_model_s_order_for_the_house_pattern(monkeypatch):
         m.close()
     assert got["cost"][0] == got["default"][0] == got["reference"][0] == 139982822016
     assert got["cost"][1] * 3 < got["default"][1]
+
+
+def test_octahedra_at_the_lowest_vertex_equal_the_general_kernels(monkeypatch):
+    """K6 minus a perfect matching on a skewed R-MAT graph of 2^13 vertices (10^9 embeddings and more): the
+    octahedron kernel (one, few and many chunks) against the fused three-level tail of the general path."""
+    off, adj = gen.rmat(13, 8, abcd=(0.7, 0.1, 0.1, 0.1), seed=3)
+    o, a = gen.csr_to_numpy(off, adj)
+    n = 1 << 13
+    monkeypatch.setenv("GPM_NO_OCTA", "1")
+    m = binding.Matcher(1)
+    m.upload(n, o, a)
+    m.set_pattern(gen.PATTERNS["k6_minus_pm"])
+    want = m.findMatches(count_only=True)
+    assert m.stats().kernel_launches[KIND_OCTA] == 0
+    m.close()
+    monkeypatch.delenv("GPM_NO_OCTA")
+    m = binding.Matcher(1)
+    m.upload(n, o, a)
+    m.set_pattern(gen.PATTERNS["k6_minus_pm"])
+    for chunks in (1, 8, 200):
+        m.set_chunks(chunks)
+        assert m.findMatches(count_only=True) == want, chunks
+    assert m.stats().kernel_launches[KIND_OCTA] > 0
+    m.close()
