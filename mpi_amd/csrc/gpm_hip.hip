@@ -95,6 +95,7 @@ enum {  // slots of the per-device counter block (unsigned long long each)
     CTR_TAIL_BYTES = 19,
     CTR_EMIT = 20,
     CTR_CYC_BYTES = 21,       // merge-model bytes of the 4-cycle kernels
+    CTR_OCTA_BYTES = 22,      // bytes of the lists the octahedron kernel walks
     CTR_OVER = 30,            // [30, 33): partial matches handed back by the launches (tiers) of the three-level kernel
     CTR_KIND_BYTES = 40,      // [40, 40 + GPM_KERNEL_KINDS): bytes summed out of the clique slots, per kind
     CTR_CLQ_CLASS0 = 24,  // [24, 29): roots per size class of the clique kernel
@@ -2425,7 +2426,8 @@ static int device_search(const SearchArgs &a, DevState &d) {
             d.rows_in[0] += (uint64_t)(hi - lo);
             if ((rc = timed_begin(d, GPM_KIND_OCTA, hi - lo, s))) return rc;
             k_octa<<<(unsigned)d.octa_wgs, 256, OCTA_LDS_BYTES(d.octa_w), s>>>(d.gv, lo, hi, d.octa_queue + seq % 1024, d.octa_mask,
-                                                                              d.octa_touched, d.octa_w, d.ctr + CTR_TAIL_MATCHES);
+                                                                              d.octa_touched, d.octa_w, d.ctr + CTR_TAIL_MATCHES,
+                                                                              d.ctr + CTR_OCTA_BYTES);
             HIP_TRY(hipGetLastError());
             if ((rc = timed_end(d, s))) return rc;
             seq++;
@@ -2587,6 +2589,7 @@ static int device_search(const SearchArgs &a, DevState &d) {
     d.bytes_kind[GPM_KIND_TAIL] = d.ctr_host[CTR_TAIL_BYTES];
     d.bytes_kind[GPM_KIND_EXTEND] = d.ctr_host[CTR_BYTES];
     d.bytes_kind[GPM_KIND_CYCLE4] = d.ctr_host[CTR_CYC_BYTES];
+    d.bytes_kind[GPM_KIND_OCTA] = d.ctr_host[CTR_OCTA_BYTES];
     for (int kd : {GPM_KIND_CLIQUE, GPM_KIND_CLQ_BUILD, GPM_KIND_CLQ_COUNT})
         d.bytes_kind[kd] = d.ctr_host[CTR_KIND_BYTES + kd];
     d.tail_bytes = 0;

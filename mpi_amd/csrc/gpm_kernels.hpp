@@ -2670,7 +2670,7 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
 
 __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t hi, unsigned long long *queue,
                                               uint32_t *mask_all, int32_t *touched_all, int W,
-                                              unsigned long long *n_copies) {
+                                              unsigned long long *n_copies, unsigned long long *alg_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ long long s_root;
     __shared__ int s_nt;
@@ -2685,7 +2685,7 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
     int32_t *touched = touched_all + (size_t)blockIdx.x * (size_t)g.n;
     const int64_t *off = g.off[0], *mid = g.mid[0];
     const int32_t *adj = g.adj[0];
-    uint64_t acc = 0;
+    uint64_t acc = 0, bytes = 0;  // bytes: the root, its higher neighbours and every list entry walked, 4 each
     for (;;) {
         __syncthreads();  // the last root is done with s_root, s_nt and the LDS rows
         if (tid == 0) {
@@ -2707,6 +2707,7 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
             const int64_t e = off[mvert + 1];
             const int64_t b = lower_bound_g(adj, off[mvert], e, u + 1);
             const uint32_t bit = 1u << (x & 31);
+            if (lane == 0) bytes += 4ull * (uint64_t)(e - b) + 4ull + (x == 0 ? 4ull : 0ull);
             for (int64_t p = b + lane; p < e; p += GPM_WAVE) {
                 const int32_t t = adj[p];
                 uint32_t *mt = mask + (size_t)t * (size_t)stride;
@@ -2804,6 +2805,7 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
         }
     }
     if (lane == 0 && acc) atomicAdd(n_copies, (unsigned long long)acc);
+    if (lane == 0 && bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
 }
 
 // Longest N+ of the graph (the universes of the clique and octahedron kernels).

@@ -18,11 +18,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
-SEARCH = ("k_clique", "k_clq_", "k_cycle4", "k_tail", "k_leaf_pair", "k_extend", "k_ranges", "k_filter_roots", "k_batch_end",
+SEARCH = ("k_clique", "k_clq_", "k_cycle4", "k_octa", "k_tail", "k_leaf_pair", "k_extend", "k_ranges", "k_filter_roots", "k_batch_end",
           "k_sum_slots")
 # kernel family (the names gpm_hip_kernel_name returns) -> prefixes of the kernels in it
 FAMILIES = {"k_tail": ("k_tail", "k_leaf_pair"), "k_extend": ("k_extend",), "k_clique": ("k_clique<", "k_clique_tiny<"),
-            "k_clq_build": ("k_clq_build",), "k_clq_count4": ("k_clq_count4",), "k_cycle4": ("k_cycle4_light", "k_cycle4_heavy", "k_cycle4_ranges")}
+            "k_clq_build": ("k_clq_build",), "k_clq_count4": ("k_clq_count4",), "k_cycle4": ("k_cycle4_light", "k_cycle4_heavy", "k_cycle4_ranges"), "k_octa": ("k_octa",)}
 
 
 def fingerprint():
