@@ -140,7 +140,8 @@ LARGE_PATHS = {
                  ({"GPM_CLIQUE_SMALL_MAX": "24"}, False, (KIND_CLQ_BUILD,))],
     # octahedra counted at the lowest vertex of a copy (masks over N+(u), few and many workgroups), and the
     # general kernels (fused three-level tail)
-    "k6_minus_pm": [({}, True, (KIND_OCTA,)), ({"GPM_OCTA_BLOCKS": "64"}, True, (KIND_OCTA,)), ({"GPM_NO_OCTA": "1"}, True, ())],
+    "k6_minus_pm": [({}, True, (KIND_OCTA,)), ({"GPM_OCTA_BLOCKS": "64"}, True, (KIND_OCTA,)), ({"GPM_NO_OCTA": "1"}, True, ()),
+                    ({"GPM_OCTA_MEM_GB": "0"}, True, ())],  # no memory for the masks: the general kernels take over
     # heavy roots as spans of two-paths on counter arrays in global memory; the heaviest with their counters
     # in LDS, one workgroup per range of ids (dozens of narrow ranges) and, with several arc blocks per root,
     # the blocks' counts merged through the root's array in global memory
@@ -163,7 +164,7 @@ def test_large_goldens(spec, monkeypatch):
     for env, accounting, kinds in LARGE_PATHS.get(spec["pattern"], [({}, True, ())]):
         for k in ("GPM_CLIQUE_SMALL_MAX", "GPM_CLQ_LISTS_MAX_CLASS", "GPM_COUNT4_WAVES", "GPM_CYCLE4_HEAVY", "GPM_CLQ_KAPPA4",
                   "GPM_CLQ_LISTS_WAVES", "GPM_CLIQUE_TINY", "GPM_CYC_RANGE_IDS", "GPM_CYC_RANGES",
-                  "GPM_CYC_RANGES_FROM", "GPM_CYC_RANGE_TILES", "GPM_CYC_RANGE_WORK", "GPM_OCTA_BLOCKS", "GPM_NO_OCTA"):
+                  "GPM_CYC_RANGES_FROM", "GPM_CYC_RANGE_TILES", "GPM_CYC_RANGE_WORK", "GPM_OCTA_BLOCKS", "GPM_NO_OCTA", "GPM_OCTA_MEM_GB"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
