@@ -2700,6 +2700,7 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
         const int d = (int)(off[u + 1] - ub);
         if (d < 4) continue;
         for (int x = tid; x < d; x += 256) U[x] = adj[ub + x];
+        const bool one_word = d <= 32;
         __syncthreads();
         // masks: member x sets its bit in the mask of every neighbour above u (lists ascend: entered above u)
         for (int x = wave; x < d; x += 4) {
@@ -2711,8 +2712,10 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
             for (int64_t p = b + lane; p < e; p += GPM_WAVE) {
                 const int32_t t = adj[p];
                 uint32_t *mt = mask + (size_t)t * (size_t)stride;
-                // word W of a mask says which of its words hold bits; who finds it empty lists the vertex
-                if (atomicOr(mt + (x >> 5), bit) == 0u && atomicOr(mt + W, 1u << (x >> 5)) == 0u) touched[atomicAdd(&s_nt, 1)] = t;
+                // word W of a mask says which of its words hold bits; who finds it empty lists the vertex.  A
+                // universe of at most 32 vertices has one-word masks: the word itself tells.
+                if (atomicOr(mt + (x >> 5), bit) == 0u && (one_word || atomicOr(mt + W, 1u << (x >> 5)) == 0u))
+                    touched[atomicAdd(&s_nt, 1)] = t;
             }
         }
         __syncthreads();
@@ -2735,7 +2738,7 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
                 const int32_t t = __hip_atomic_load(touched + z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 uint32_t *mt = mask + (size_t)t * (size_t)stride;
                 // only the words that hold bits are read (one, for most vertices)
-                const uint32_t filled = __hip_atomic_load(mt + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t filled = one_word ? 1u : __hip_atomic_load(mt + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int w = 0; w < OCTA_MAX_D / 32; ++w)
                     mw[w] = (filled >> w) & 1u ? __hip_atomic_load(mt + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -2744,7 +2747,7 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
                     k += __popc(mw[w]);
                     if (mw[w]) atomicExch(mt + w, 0u);  // cleared for the next root
                 }
-                atomicExch(mt + W, 0u);
+                if (!one_word) atomicExch(mt + W, 0u);
             } else {
 #pragma unroll
                 for (int w = 0; w < OCTA_MAX_D / 32; ++w) mw[w] = 0;
