@@ -2203,10 +2203,11 @@ static int ensure_octa(gpm_ctx *ctx, DevState &d) {
     if (max_plus > OCTA_MAX_D) return GPM_OK;
     const int W = std::max(1, (max_plus + 31) / 32);
     const int64_t budget = env_i64("GPM_OCTA_MEM_GB", 16) << 30;
-    const int64_t per_wg = n * (int64_t)(W + 2) * 4;
+    const int64_t mask_stride = (W + 2) & ~1;  // as k_octa lays the masks out
+    const int64_t per_wg = n * (mask_stride + 1) * 4;
     const int64_t wgs = std::min<int64_t>(env_i64("GPM_OCTA_BLOCKS", 1024), per_wg > 0 ? budget / per_wg : 0);
     if (wgs < 64) return GPM_OK;
-    const size_t mask_bytes = (size_t)wgs * (size_t)n * (size_t)(W + 1) * sizeof(uint32_t);
+    const size_t mask_bytes = (size_t)wgs * (size_t)n * (size_t)mask_stride * sizeof(uint32_t);
     if (hipMalloc(&d.octa_mask, mask_bytes) != hipSuccess || hipMalloc(&d.octa_touched, (size_t)wgs * (size_t)n * sizeof(int32_t)) != hipSuccess ||
         hipMalloc(&d.octa_queue, 1024 * sizeof(unsigned long long)) != hipSuccess) {
         (void)hipGetLastError();

@@ -2655,7 +2655,7 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
 //
 // One workgroup per root u, roots taken from a queue.  Every vertex t above u gets a bit mask over the
 // positions of U: the members of U adjacent to t.  The masks live in a slab of global memory that belongs
-// to the workgroup ((W + 1) words per vertex of the graph, all zero between roots): the waves walk the lists
+// to the workgroup (W + 1 words per vertex of the graph, rounded up to an even number, all zero between roots): the waves walk the lists
 // of U's members above u and OR the member's bit into the mask of every entry (atomics in L2; word W of a
 // mask says which of its words hold bits, and who finds it empty appends the vertex to the workgroup's list
 // of touched vertices).  The
@@ -2680,7 +2680,7 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
     const int Wr = OCTA_ROW_WORDS(W), Wq = Wr / 4;
     uint16_t *members = (uint16_t *)(smem + OCTA_MAX_D + OCTA_MAX_D * Wr + wave * (OCTA_MAX_D / 2 + Wr));
     uint32_t *wmask = smem + OCTA_MAX_D + OCTA_MAX_D * Wr + wave * (OCTA_MAX_D / 2 + Wr) + OCTA_MAX_D / 2;
-    const int stride = W + 1;
+    const int stride = (W + 2) & ~1;  // even: the first two words of a mask are also one 64-bit word
     uint32_t *mask = mask_all + (size_t)blockIdx.x * (size_t)g.n * (size_t)stride;
     int32_t *touched = touched_all + (size_t)blockIdx.x * (size_t)g.n;
     const int64_t *off = g.off[0], *mid = g.mid[0];
@@ -2700,7 +2700,7 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
         const int d = (int)(off[u + 1] - ub);
         if (d < 4) continue;
         for (int x = tid; x < d; x += 256) U[x] = adj[ub + x];
-        const bool one_word = d <= 32;
+        const bool one_word = d <= 64;
         __syncthreads();
         // masks: member x sets its bit in the mask of every neighbour above u (lists ascend: entered above u)
         for (int x = wave; x < d; x += 4) {
@@ -2713,9 +2713,11 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
                 const int32_t t = adj[p];
                 uint32_t *mt = mask + (size_t)t * (size_t)stride;
                 // word W of a mask says which of its words hold bits; who finds it empty lists the vertex.  A
-                // universe of at most 32 vertices has one-word masks: the word itself tells.
-                if (atomicOr(mt + (x >> 5), bit) == 0u && (one_word || atomicOr(mt + W, 1u << (x >> 5)) == 0u))
-                    touched[atomicAdd(&s_nt, 1)] = t;
+                // universe of at most 64 vertices has masks of one 64-bit word: the word itself tells.
+                bool first;
+                if (one_word) first = atomicOr(reinterpret_cast<unsigned long long *>(mt), 1ull << x) == 0ull;
+                else first = atomicOr(mt + (x >> 5), bit) == 0u && atomicOr(mt + W, 1u << (x >> 5)) == 0u;
+                if (first) touched[atomicAdd(&s_nt, 1)] = t;
             }
         }
         __syncthreads();
@@ -2738,7 +2740,7 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
                 const int32_t t = __hip_atomic_load(touched + z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 uint32_t *mt = mask + (size_t)t * (size_t)stride;
                 // only the words that hold bits are read (one, for most vertices)
-                const uint32_t filled = one_word ? 1u : __hip_atomic_load(mt + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t filled = one_word ? 3u : __hip_atomic_load(mt + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int w = 0; w < OCTA_MAX_D / 32; ++w)
                     mw[w] = (filled >> w) & 1u ? __hip_atomic_load(mt + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
