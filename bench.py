@@ -478,6 +478,19 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, many_budget_s=args.cpu_many_budget, forced_many=args.cpu_ranks)
+            # beside the reference on its sample: what an independent counting program needed on the host for
+            # this configuration at FULL size (a recorded run, not timed here; it counts, the reference and the
+            # GPU's output mode enumerate)
+            full_path = os.path.join(ROOT, "tests", "golden", "full_size_counts.json")
+            if not overridden and os.path.exists(full_path):
+                with open(full_path) as f:
+                    rec = json.load(f)["configs"].get(str(args.config))
+                if rec and rec.get("seconds"):
+                    line["cpu_baseline"]["independent_count_full_size"] = {
+                        "seconds": rec["seconds"], "threads": rec.get("threads", 1),
+                        "matches_per_s": rec["embeddings"] / rec["seconds"],
+                        "program": rec.get("counter", "oracle/clique_count.c"),
+                        "note": "recorded by tests/golden/make_full_size_counts.py on the GPU box's host cores"}
         print(json.dumps(line), flush=True)
         if want is not None and total != want:
             log(f"COUNT MISMATCH: counted {total}, expected {want} ({want_src})")
