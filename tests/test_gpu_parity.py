@@ -741,7 +741,7 @@ def test_several_workers_in_one_context(workers, gather, monkeypatch):
     if gather == "device_small_rounds":
         monkeypatch.setenv("GPM_CHUNK_ROOTS", "64")
         monkeypatch.setenv("GPM_EMIT_ROWS", "3000")
-    for name in ("rmat10_clique4", "rmat8_house", "rmat10_cycle4", "plaw9_tree5_labelled4"):
+    for name in ("rmat10_clique4", "rmat8_house", "rmat10_cycle4", "plaw9_tree5_labelled4", "skew9_k6_minus_pm"):
         spec = next(g for g in GOLDEN if g["name"] == name)
         n, s, d = util.build_graph(spec)
         dl, pl = util.build_labels(spec, n)
