@@ -2655,7 +2655,8 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
 //
 // One workgroup per root u, roots taken from a queue.  Every vertex t above u gets a bit mask over the
 // positions of U: the members of U adjacent to t.  The masks live in a slab of global memory that belongs
-// to the workgroup (W + 1 words per vertex of the graph, rounded up to an even number, all zero between roots): the waves walk the lists
+// to the workgroup (room for W + 1 words per vertex of the graph, rounded up to an even number, all zero between
+// roots; a root uses only as many words per vertex as its own universe needs): the waves walk the lists
 // of U's members above u and OR the member's bit into the mask of every entry (atomics in L2; word W of a
 // mask says which of its words hold bits, and who finds it empty appends the vertex to the workgroup's list
 // of touched vertices).  The
@@ -2663,10 +2664,10 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
 // every touched vertex t with at least four bits is a u': a wave lists the members of its mask and its lanes
 // take the pairs {x, y}, three-way AND of two LDS rows and the mask.  Masks are cleared as they are used.
 // Universes of up to OCTA_MAX_D vertices; the caller checks the longest N+ and the memory for the slabs.
-// Dynamic LDS (words), Wr = W rounded up to 4: U[OCTA_MAX_D] | rows[OCTA_MAX_D * Wr] | per wave: members[OCTA_MAX_D / 2] (16-bit) | mask[Wr].
+// Dynamic LDS (words), Wr = W rounded up to 4: U[OCTA_MAX_D] | rows[OCTA_MAX_D * Wr] | per wave: members[OCTA_MAX_D / 2] (16-bit).
 #define OCTA_MAX_D 512
-#define OCTA_ROW_WORDS(W) (((W) + 3) & ~3)  // rows and the wave's mask copy are read 16 bytes at a time
-#define OCTA_LDS_BYTES(W) ((OCTA_MAX_D + OCTA_MAX_D * OCTA_ROW_WORDS(W) + 4 * (OCTA_MAX_D / 2 + OCTA_ROW_WORDS(W))) * 4)
+#define OCTA_ROW_WORDS(W) (((W) + 3) & ~3)  // rows are read 16 bytes at a time
+#define OCTA_LDS_BYTES(W) ((OCTA_MAX_D + OCTA_MAX_D * OCTA_ROW_WORDS(W) + 4 * (OCTA_MAX_D / 2)) * 4)
 
 __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t hi, unsigned long long *queue,
                                               uint32_t *mask_all, int32_t *touched_all, int W,
@@ -2677,15 +2678,17 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
     int32_t *U = (int32_t *)smem;
     uint32_t *rows = smem + OCTA_MAX_D;
-    const int Wr = OCTA_ROW_WORDS(W), Wq = Wr / 4;
-    uint16_t *members = (uint16_t *)(smem + OCTA_MAX_D + OCTA_MAX_D * Wr + wave * (OCTA_MAX_D / 2 + Wr));
-    uint32_t *wmask = smem + OCTA_MAX_D + OCTA_MAX_D * Wr + wave * (OCTA_MAX_D / 2 + Wr) + OCTA_MAX_D / 2;
+    const int Wr = OCTA_ROW_WORDS(W);
+    uint16_t *members = (uint16_t *)(smem + OCTA_MAX_D + OCTA_MAX_D * Wr + wave * (OCTA_MAX_D / 2));
     const int stride = (W + 2) & ~1;  // even: the first two words of a mask are also one 64-bit word
     uint32_t *mask = mask_all + (size_t)blockIdx.x * (size_t)g.n * (size_t)stride;
     int32_t *touched = touched_all + (size_t)blockIdx.x * (size_t)g.n;
     const int64_t *off = g.off[0], *mid = g.mid[0];
     const int32_t *adj = g.adj[0];
-    uint64_t acc = 0, bytes = 0;  // bytes: the root, its higher neighbours and every list entry walked, 4 each
+    uint64_t bytes = 0;  // the root, its higher neighbours and every list entry walked, 4 each
+    // Every 4-cycle of a set T is found at both of its diagonals: the lanes add what their pairs find, and
+    // the sum over the wave -- whole sets only, so an even number -- is halved at the end.
+    uint64_t twice = 0;
     for (;;) {
         __syncthreads();  // the last root is done with s_root, s_nt and the LDS rows
         if (tid == 0) {
@@ -2701,6 +2704,13 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
         if (d < 4) continue;
         for (int x = tid; x < d; x += 256) U[x] = adj[ub + x];
         const bool one_word = d <= 64;
+        // This root's masks are as wide as its universe (Wd words and the flag word, none for one 64-bit
+        // word) and lie that close together in the slab: the narrower, the more of them share a cache line.
+        // The slab is all zero between roots, so every root may lay it out anew.
+        const int Wd = (d + 31) >> 5;
+        const int Wrd = OCTA_ROW_WORDS(Wd), Wqd = Wrd / 4;  // the LDS rows are as wide as the universe, too
+        const bool half_word = d <= 32;  // one 32-bit word: twice as many masks to a cache line again
+        const int rstride = half_word ? 1 : one_word ? 2 : (Wd + 2) & ~1;
         __syncthreads();
         // masks: member x sets its bit in the mask of every neighbour above u (lists ascend: entered above u)
         for (int x = wave; x < d; x += 4) {
@@ -2711,21 +2721,22 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
             if (lane == 0) bytes += 4ull * (uint64_t)(e - b) + 4ull + (x == 0 ? 4ull : 0ull);
             for (int64_t p = b + lane; p < e; p += GPM_WAVE) {
                 const int32_t t = adj[p];
-                uint32_t *mt = mask + (size_t)t * (size_t)stride;
-                // word W of a mask says which of its words hold bits; who finds it empty lists the vertex.  A
+                uint32_t *mt = mask + (size_t)t * (size_t)rstride;
+                // word Wd of a mask says which of its words hold bits; who finds it empty lists the vertex.  A
                 // universe of at most 64 vertices has masks of one 64-bit word: the word itself tells.
                 bool first;
-                if (one_word) first = atomicOr(reinterpret_cast<unsigned long long *>(mt), 1ull << x) == 0ull;
-                else first = atomicOr(mt + (x >> 5), bit) == 0u && atomicOr(mt + W, 1u << (x >> 5)) == 0u;
+                if (half_word) first = atomicOr(mt, bit) == 0u;
+                else if (one_word) first = atomicOr(reinterpret_cast<unsigned long long *>(mt), 1ull << x) == 0ull;
+                else first = atomicOr(mt + (x >> 5), bit) == 0u && atomicOr(mt + Wd, 1u << (x >> 5)) == 0u;
                 if (first) touched[atomicAdd(&s_nt, 1)] = t;
             }
         }
         __syncthreads();
         const int nt = s_nt;
         // the masks of U's members are the adjacency inside U (read past the L1: they were written by atomics)
-        for (int x = tid; x < d * Wr; x += 256) {
-            const int i = x / Wr, w = x - i * Wr;
-            rows[x] = w < W ? __hip_atomic_load(mask + (size_t)U[i] * (size_t)stride + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        for (int x = tid; x < d * Wrd; x += 256) {
+            const int i = x / Wrd, w = x - i * Wrd;
+            rows[x] = w < Wd ? __hip_atomic_load(mask + (size_t)U[i] * (size_t)rstride + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         }
         __syncthreads();
         // Most touched vertices are adjacent to fewer than four members.  A wave therefore takes 64 touched
@@ -2738,9 +2749,9 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
             int k = 0;
             if (z < nt) {
                 const int32_t t = __hip_atomic_load(touched + z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t *mt = mask + (size_t)t * (size_t)stride;
+                uint32_t *mt = mask + (size_t)t * (size_t)rstride;
                 // only the words that hold bits are read (one, for most vertices)
-                const uint32_t filled = one_word ? 3u : __hip_atomic_load(mt + W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t filled = half_word ? 1u : one_word ? 3u : __hip_atomic_load(mt + Wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int w = 0; w < OCTA_MAX_D / 32; ++w)
                     mw[w] = (filled >> w) & 1u ? __hip_atomic_load(mt + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -2749,7 +2760,7 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
                     k += __popc(mw[w]);
                     if (mw[w]) atomicExch(mt + w, 0u);  // cleared for the next root
                 }
-                if (!one_word) atomicExch(mt + W, 0u);
+                if (!one_word) atomicExch(mt + Wd, 0u);
             } else {
 #pragma unroll
                 for (int w = 0; w < OCTA_MAX_D / 32; ++w) mw[w] = 0;
@@ -2758,31 +2769,26 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
             while (big) {
                 const int src = __builtin_ctzll(big);
                 big &= big - 1;
-                wave_lds_sync();
-                if (lane == src) {
+                // the set's mask, the same in every lane (words from Wd on are zeros)
+                uint32_t um[OCTA_MAX_D / 32];
 #pragma unroll
-                    for (int w = 0; w < OCTA_MAX_D / 32; ++w)
-                        if (w < Wr) wmask[w] = mw[w];  // words from W on are zeros
-                }
-                wave_lds_sync();
-                const uint32_t mine = lane < W ? wmask[lane] : 0u;
+                for (int w = 0; w < OCTA_MAX_D / 32; ++w) um[w] = __builtin_amdgcn_readlane(mw[w], src);
                 const int kk = __builtin_amdgcn_readlane(k, src);
+                wave_lds_sync();  // the last set's pairs are done with members[]
                 {  // positions of the mask's bits, in ascending order: lane l lists the bits of word l
-                    const int before = __popc(mine);
-                    int incl = before;
-                    for (int o = 1; o < GPM_WAVE; o <<= 1) {
-                        const int up = __shfl_up(incl, o, GPM_WAVE);
-                        if (lane >= o) incl += up;
+                    int at = 0;
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int w = 0; w < OCTA_MAX_D / 32; ++w) {
+                        if (lane > w) at += __popc(um[w]);
+                        if (lane == w) bits = um[w];
                     }
-                    int at = incl - before;
-                    uint32_t bits = mine;
                     while (bits) {
                         members[at++] = (uint16_t)(32 * lane + __builtin_ctz(bits));
                         bits &= bits - 1;
                     }
                 }
                 wave_lds_sync();
-                uint64_t twice = 0;  // every 4-cycle of T is found at both of its diagonals
                 // The kk (kk - 1) / 2 pairs are dealt out to the lanes as one sequence (row p holds the pairs
                 // (p, p + 1) .. (p, kk - 1)): most sets are small, and a lane per pair of one row at a time
                 // would leave most lanes idle.  A lane keeps its place as (p, r) = r-th pair of row p.
@@ -2792,11 +2798,13 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
                     ++pp;
                 }
                 while (pp < kk - 1) {
-                    const uint32_t *rp = rows + (int)members[pp] * Wr, *rq = rows + (int)members[pp + 1 + r] * Wr;
+                    const uint32_t *rp = rows + (int)members[pp] * Wrd, *rq = rows + (int)members[pp + 1 + r] * Wrd;
                     uint32_t c = 0;
 #pragma unroll
                     for (int v = 0; v < OCTA_MAX_D / 128; ++v)
-                        if (v < Wq) c = and_popc_add4(and4(load4(rp + 4 * v), load4(wmask + 4 * v)), load4(rq + 4 * v), c);
+                        if (v < Wqd)
+                            c = and_popc_add4(and4(load4(rp + 4 * v), u32x4{um[4 * v], um[4 * v + 1], um[4 * v + 2], um[4 * v + 3]}),
+                                              load4(rq + 4 * v), c);
                     twice += (uint64_t)c * (c - (c ? 1u : 0u)) / 2;
                     r += GPM_WAVE;
                     while (pp < kk - 1 && r >= kk - 1 - pp) {
@@ -2804,12 +2812,11 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
                         ++pp;
                     }
                 }
-                twice = wave_sum_u64(twice);
-                if (lane == 0) acc += twice / 2;
             }
         }
     }
-    if (lane == 0 && acc) atomicAdd(n_copies, (unsigned long long)acc);
+    twice = wave_sum_u64(twice);
+    if (lane == 0 && twice) atomicAdd(n_copies, (unsigned long long)(twice / 2));
     if (lane == 0 && bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
 }
 
