@@ -2664,10 +2664,11 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
 // every touched vertex t with at least four bits is a u': a wave lists the members of its mask and its lanes
 // take the pairs {x, y}, three-way AND of two LDS rows and the mask.  Masks are cleared as they are used.
 // Universes of up to OCTA_MAX_D vertices; the caller checks the longest N+ and the memory for the slabs.
-// Dynamic LDS (words), Wr = W rounded up to 4: U[OCTA_MAX_D] | rows[OCTA_MAX_D * Wr] | per wave: members[OCTA_MAX_D / 2] (16-bit).
+// Dynamic LDS (words), D = 32 W (the graph's longest N+ rounded up), Wr = W rounded up to 4:
+// U[D] | rows[D * Wr] | per wave: members[D / 2] (16-bit).
 #define OCTA_MAX_D 512
 #define OCTA_ROW_WORDS(W) (((W) + 3) & ~3)  // rows are read 16 bytes at a time
-#define OCTA_LDS_BYTES(W) ((OCTA_MAX_D + OCTA_MAX_D * OCTA_ROW_WORDS(W) + 4 * (OCTA_MAX_D / 2)) * 4)
+#define OCTA_LDS_BYTES(W) ((32 * (W) + 32 * (W) * OCTA_ROW_WORDS(W) + 4 * (32 * (W) / 2)) * 4)
 
 __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t hi, unsigned long long *queue,
                                               uint32_t *mask_all, int32_t *touched_all, int W,
@@ -2677,9 +2678,9 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
     __shared__ int s_nt;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
     int32_t *U = (int32_t *)smem;
-    uint32_t *rows = smem + OCTA_MAX_D;
-    const int Wr = OCTA_ROW_WORDS(W);
-    uint16_t *members = (uint16_t *)(smem + OCTA_MAX_D + OCTA_MAX_D * Wr + wave * (OCTA_MAX_D / 2));
+    const int Dcap = 32 * W, Wr = OCTA_ROW_WORDS(W);
+    uint32_t *rows = smem + Dcap;
+    uint16_t *members = (uint16_t *)(smem + Dcap + Dcap * Wr + wave * (Dcap / 2));
     const int stride = (W + 2) & ~1;  // even: the first two words of a mask are also one 64-bit word
     uint32_t *mask = mask_all + (size_t)blockIdx.x * (size_t)g.n * (size_t)stride;
     int32_t *touched = touched_all + (size_t)blockIdx.x * (size_t)g.n;
@@ -2709,6 +2710,9 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
         // The slab is all zero between roots, so every root may lay it out anew.
         const int Wd = (d + 31) >> 5;
         const int Wrd = OCTA_ROW_WORDS(Wd), Wqd = Wrd / 4;  // the LDS rows are as wide as the universe, too
+        // rows lie an odd number of 16-byte pieces apart where that fits: piece v of rows r and r + 8 would
+        // share its banks at a stride of 8 words
+        const int Wsd = (Wrd | 4) * d <= Dcap * Wr ? (Wrd | 4) : Wrd;
         const bool half_word = d <= 32;  // one 32-bit word: twice as many masks to a cache line again
         const int rstride = half_word ? 1 : one_word ? 2 : (Wd + 2) & ~1;
         __syncthreads();
@@ -2736,7 +2740,7 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
         // the masks of U's members are the adjacency inside U (read past the L1: they were written by atomics)
         for (int x = tid; x < d * Wrd; x += 256) {
             const int i = x / Wrd, w = x - i * Wrd;
-            rows[x] = w < Wd ? __hip_atomic_load(mask + (size_t)U[i] * (size_t)rstride + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            rows[i * Wsd + w] = w < Wd ? __hip_atomic_load(mask + (size_t)U[i] * (size_t)rstride + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         }
         __syncthreads();
         // Most touched vertices are adjacent to fewer than four members.  A wave therefore takes 64 touched
@@ -2798,7 +2802,7 @@ __global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t h
                     ++pp;
                 }
                 while (pp < kk - 1) {
-                    const uint32_t *rp = rows + (int)members[pp] * Wrd, *rq = rows + (int)members[pp + 1 + r] * Wrd;
+                    const uint32_t *rp = rows + (int)members[pp] * Wsd, *rq = rows + (int)members[pp + 1 + r] * Wsd;
                     uint32_t c = 0;
 #pragma unroll
                     for (int v = 0; v < OCTA_MAX_D / 128; ++v)

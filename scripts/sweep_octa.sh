@@ -2,6 +2,6 @@ run() { env "$@" timeout -k 10 300 python3 bench.py --config 5 --steps 3 --warmu
 run GPM_OCTA_BLOCKS=256
 run GPM_OCTA_BLOCKS=512
 run GPM_OCTA_BLOCKS=1024
+run GPM_OCTA_BLOCKS=1280
+run GPM_OCTA_BLOCKS=1536 GPM_OCTA_MEM_GB=32
 run GPM_OCTA_BLOCKS=2048 GPM_OCTA_MEM_GB=32
-run GPM_CHUNKS=8
-run GPM_CHUNKS=256
