@@ -354,6 +354,24 @@ def test_cliques_in_complete_graphs_closed_form(n, pname):
     m.close()
 
 
+@pytest.mark.parametrize("n", [40, 70, 140, 300, 513])
+def test_octahedra_in_complete_graphs_closed_form(n):
+    """K_n holds n!/(n-6)! embeddings of K6 minus a perfect matching (every injective map of six vertices).
+    The roots' universes run through every size below n: masks of one 32-bit word, of one 64-bit word and of
+    several words with a flag word, LDS rows of 4, 8, 12 and 16 words (n = 513: the largest universe the
+    octahedron kernel takes)."""
+    s, d = complete_graph(n)
+    want = 1
+    for i in range(6):
+        want *= n - i
+    m = binding.Matcher(1)
+    upload(m, n, s, d)
+    m.set_pattern(gen.PATTERNS["k6_minus_pm"])
+    assert m.findMatches(count_only=True) == want
+    assert m.stats().kernel_launches[KIND_OCTA] > 0
+    m.close()
+
+
 def test_two_path_counting_of_four_cycles_equals_the_generic_path(monkeypatch):
     """R-MAT scale 16 with one, few and many chunks: heavy roots (whole grid), light roots (one
     workgroup, counter array) and tiny roots (one wave, registers; only taken when a chunk holds
