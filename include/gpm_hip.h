@@ -103,6 +103,8 @@ typedef struct {
     int32_t simple;      /* no duplicate arcs and no self loops */
     int32_t max_out_deg, max_in_deg;
     int32_t has_labels;
+    int32_t hub_rows;    /* rows of the dense bitmap over the highest-degree vertices on GPU 0 (0: none was
+                          * allocated; every kernel then tests membership in the lists) */
 } gpm_graph_info;
 
 /* Kernel families the search is made of; indices of the kernel_* arrays of gpm_stats. */
@@ -231,7 +233,10 @@ int gpm_hip_search_text(gpm_ctx *ctx, gpm_text_sink sink, void *user, uint64_t *
  * gpm_hip_stats reports no kernel times after it).  It runs the level-by-level
  * and fused-intersection kernels only.  Limits: one GPU per context; longest
  * adjacency list (either direction) at most 65472 entries, else GPM_EINVAL
- * with a message.  Every call on one GPU shares that GPU's array: calls that
+ * with a message; a context that shares its chunk cursor with other processes
+ * (gpm_hip_set_cursor) is rejected with GPM_ESTATE, because this call walks
+ * every root of the range itself and the processes' counts would no longer add
+ * up to the whole.  Every call on one GPU shares that GPU's array: calls that
  * overlap on one GPU (from any context or thread) race. */
 int gpm_hip_count_noalloc(gpm_ctx *ctx, uint64_t *total);
 

@@ -46,7 +46,7 @@ class gpm_plan(ctypes.Structure):
 class gpm_graph_info(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("m_out", ctypes.c_int64), ("symmetric", ctypes.c_int32),
                 ("simple", ctypes.c_int32), ("max_out_deg", ctypes.c_int32), ("max_in_deg", ctypes.c_int32),
-                ("has_labels", ctypes.c_int32)]
+                ("has_labels", ctypes.c_int32), ("hub_rows", ctypes.c_int32)]
 
 
 class gpm_stats(ctypes.Structure):

@@ -260,6 +260,8 @@ struct gpm_ctx {
     uint64_t cyc_single_ver = 0;
     int64_t chunk_roots = 1 << 20;  // upper bound of a chunk's size
     int64_t chunk_hint = 0;         // how many chunks to aim for (0 = 32 per GPU of the context)
+    int64_t min_chunk_cost = (int64_t)1 << 22;  // GPM_MIN_CHUNK_COST: least estimated work of a chunk, in the units of
+                                                // k_root_cost / two-paths (tests set 1 to cut tiny graphs into many chunks)
     std::vector<Chunk> chunks;
     bool chunks_valid = false;
     int64_t root_lo = 0, root_hi = 0;
@@ -563,6 +565,7 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->chunk_roots = env_i64("GPM_CHUNK_ROOTS", 1 << 20);
     if (ctx->chunk_roots < 1) ctx->chunk_roots = 1;
     ctx->chunk_hint = env_i64("GPM_CHUNKS", 0);
+    ctx->min_chunk_cost = std::max<int64_t>(1, env_i64("GPM_MIN_CHUNK_COST", (int64_t)1 << 22));
     ctx->use_tail = env_i64("GPM_NO_TAIL", 0) == 0;
     ctx->use_clique = env_i64("GPM_NO_CLIQUE", 0) == 0;
     ctx->use_cycle4 = env_i64("GPM_NO_CYCLE4", 0) == 0;
@@ -667,10 +670,10 @@ static int rebuild_direction(DevState &d, int dir, const int64_t *old_off, const
         HIP_TRY(tmp.alloc(tmp_bytes));
         HIP_TRY(rocprim::radix_sort_keys(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), (size_t)m, 0u,
                                          end_bit, s));
-        k_keys_to_adj<<<grid_for(m), 256, 0, s>>>(m, keys2.as<uint64_t>(), d.adj[dir]);
+        k_keys_to_adj<<<grid_for(m), 256, 0, s>>>(m, keys2.as<uint64_t>(), d.adj[dir], flags);
         HIP_TRY(hipStreamSynchronize(s));
     }
-    if (n > 0) k_mid_and_flags<<<grid_for(n), 256, 0, s>>>(n, d.off[dir], d.adj[dir], d.mid[dir], flags);
+    if (n > 0) k_mid<<<grid_for(n), 256, 0, s>>>(n, d.off[dir], d.adj[dir], d.mid[dir]);
     HIP_TRY(hipStreamSynchronize(s));
     d.m[dir] = m;
     return GPM_OK;
@@ -780,9 +783,11 @@ static int upload_one(DevState &d, int32_t n, const int64_t *out_off, const int3
         // Every kernel runs without the matrix (membership by binary search, rows from hashed list walks), so a
         // device too full for it is not an error: halve the rows until it fits, or go without.
         size_t want = bytes;
-        while (hub_rows >= 1024 && hipMalloc(&d.hub, want) != hipSuccess) {
+        for (;;) {  // a small matrix (a small graph, a low GPM_HUB_ROWS) is tried like any other: only retries halve
+            if (hipMalloc(&d.hub, want) == hipSuccess) break;
             (void)hipGetLastError();
             d.hub = nullptr;
+            if (hub_rows < 2048) break;
             hub_rows = hub_rows / 2 / 64 * 64;
             want = (size_t)hub_rows * (size_t)(hub_rows / 32) * sizeof(uint32_t);
         }
@@ -896,6 +901,7 @@ extern "C" int gpm_hip_upload_graph(gpm_ctx *ctx, int32_t n, const int64_t *out_
     ctx->info.max_out_deg = (int32_t)max_out;
     ctx->info.max_in_deg = (int32_t)(in_off ? max_in : max_out);
     ctx->info.has_labels = labels != nullptr;
+    ctx->info.hub_rows = ctx->devs[0].gv.hub ? ctx->devs[0].gv.hub_wpr * 32 : 0;
     ctx->root_lo = 0;
     ctx->root_hi = n;
     ctx->have_graph = true;
@@ -1256,6 +1262,7 @@ extern "C" int gpm_hip_set_plan(gpm_ctx *ctx, const gpm_plan *p) {
 
 extern "C" int gpm_hip_set_cursor(gpm_ctx *ctx, volatile uint64_t *cursor) {
     if (!ctx) return fail(GPM_EINVAL, "null context");
+    if ((ctx->shared_cursor == nullptr) != (cursor == nullptr)) ctx->chunks_valid = false;  // the chunk count depends on it
     ctx->shared_cursor = cursor;
     return GPM_OK;
 }
@@ -2297,10 +2304,14 @@ static int prepare_chunks(gpm_ctx *ctx) {
             ctx->cyc_single_v1.push_back((int32_t)(ctx->info.n - 1 - ctx->cyc_heavy_roots[h]));
         }
     int64_t want = ctx->chunk_hint > 0 ? ctx->chunk_hint : 32 * (int64_t)ctx->devs.size();
-    // the two-path counts are exact costs and every chunk is one persistent launch: few, large chunks
-    if (cyc || (ctx->octa && ctx->use_octa)) want = std::max<int64_t>(1, want / 8);
+    // The two-path counts are exact costs and every chunk is one persistent launch: few, large chunks.  Several
+    // processes on one cursor need chunks to steal from each other, so there the count is only halved.
+    if (cyc || (ctx->octa && ctx->use_octa)) want = std::max<int64_t>(1, want / (ctx->shared_cursor ? 2 : 8));
     // the level-by-level path synchronises with the host several times per chunk: fewer, larger chunks
     else if (!(ctx->clique_k && ctx->use_clique)) want = std::max<int64_t>(1, want / 8);
+    // A chunk costs the host a handful of enqueues (microseconds each) whatever it holds: a graph whose whole
+    // root set is less work than one launch deserves gets one chunk, not the hinted number.
+    want = std::min<int64_t>(want, std::max<int64_t>(1, hpref.back() / ctx->min_chunk_cost));
     const int64_t target = std::max<int64_t>(1, hpref.back() / want);
     int64_t begin = 0;
     while (begin < nroots) {
@@ -2759,6 +2770,8 @@ extern "C" int gpm_hip_count_noalloc(gpm_ctx *ctx, uint64_t *total) {
     if (!ctx->have_graph || !ctx->have_plan) return fail(GPM_ESTATE, "upload a graph and set a plan first");
     if (ctx->devs.size() != 1) return fail(GPM_EINVAL, "the no-allocation search runs on a single-GPU context");
     if (!ctx->scratch0) return fail(GPM_ESTATE, "the fixed scratch array was not located");
+    if (ctx->shared_cursor)
+        return fail(GPM_ESTATE, "the no-allocation search walks every root itself: not on a context that shares a chunk cursor");
     const int64_t cap = NOALLOC_ROWS;
     const int64_t longest = (int64_t)std::max(ctx->info.max_out_deg, ctx->info.max_in_deg);
     if (longest + 64 > cap)

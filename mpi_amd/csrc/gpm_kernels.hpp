@@ -44,24 +44,21 @@ __global__ void k_arc_keys(int32_t n, int64_t m, const int64_t *off, const int32
     keys[e] = ((uint64_t)(uint32_t)rank[lo] << 32) | (uint32_t)rank[adj[e]];
 }
 
-__global__ void k_keys_to_adj(int64_t m, const uint64_t *keys, int32_t *adj) {
+// Unpack the sorted keys into the adjacency array; one thread per arc also raises flag bit 0 for a self loop
+// (source == target) and for a duplicate arc (the key equals the one before it).
+__global__ void k_keys_to_adj(int64_t m, const uint64_t *keys, int32_t *adj, uint32_t *flags) {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < m) adj[e] = (int32_t)(uint32_t)keys[e];
+    if (e >= m) return;
+    const uint64_t key = keys[e];
+    adj[e] = (int32_t)(uint32_t)key;
+    if ((uint32_t)(key >> 32) == (uint32_t)key || (e > 0 && keys[e - 1] == key)) atomicOr(flags, 1u);
 }
 
-// mid[v] = first position of v's list holding an id > v; also raises flags
-// for self loops / duplicate arcs (bit 0) and ids out of range (bit 1).
-__global__ void k_mid_and_flags(int32_t n, const int64_t *off, const int32_t *adj, int64_t *mid, uint32_t *flags) {
+// mid[v] = first position of v's list holding an id > v.
+__global__ void k_mid(int32_t n, const int64_t *off, const int32_t *adj, int64_t *mid) {
     int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
-    int64_t b = off[v], e = off[v + 1];
-    mid[v] = lower_bound_g(adj, b, e, v + 1);
-    uint32_t f = 0;
-    for (int64_t i = b; i < e; ++i) {
-        int32_t w = adj[i];
-        if (w == v || (i > b && w == adj[i - 1])) f |= 1u;
-    }
-    if (f) atomicOr(flags, f);
+    mid[v] = lower_bound_g(adj, off[v], off[v + 1], v + 1);
 }
 
 // Validation of caller-supplied CSR before anything dereferences it.
@@ -2040,26 +2037,28 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
     const int L = 1 << lg, sub = lane & (L - 1), blk = lane >> lg;
     const bool lane_ok = 4 * sub < Wt;
     {
-        // rows copied in at a stride of L slots; the slots past a row's Wt / 4 are never read
-        const int nslots = (j_hi - j_lo) << lg, Wq = Wt >> 2;
+        // Rows copied in at a stride of L slots; the slots past a row's Wt / 4 are never read.  The copy runs
+        // over the source (one contiguous piece of nrows * Wq 16-byte words): every read of a full batch is
+        // issued without a condition, so eight of them are in flight per thread.  Only one workgroup fits a
+        // compute unit with the big tiles, and nothing else hides this copy's latency.
+        const int Wq = Wt >> 2, nsrc = (j_hi - j_lo) * Wq;
+        const uint32_t inv = (65536u + (uint32_t)Wq - 1u) / (uint32_t)Wq;  // q / Wq == (q * inv) >> 16 for q < 8192, Wq <= 8
         const uint4 *src = reinterpret_cast<const uint4 *>(tile_rows);
         uint4 *dst = reinterpret_cast<uint4 *>(tile);
-        constexpr int NT = NW * GPM_WAVE, FILL = 8;  // eight 16-byte reads in flight per thread
-        for (int k0 = tid; k0 < nslots; k0 += FILL * NT) {
-            // every read is issued whatever k is (from a clamped address): values assigned under a condition
-            // would be kept in private memory, not in registers
+        constexpr int NT = NW * GPM_WAVE, FILL = 8;
+        auto slot_of = [&](int q) {
+            const int row = (int)(((uint32_t)q * inv) >> 16);
+            return (row << lg) + (q - row * Wq);
+        };
+        int q0 = tid;
+        for (; q0 + (FILL - 1) * NT < nsrc; q0 += FILL * NT) {
             uint4 v[FILL];
 #pragma unroll
-            for (int f = 0; f < FILL; ++f) {
-                const int k = min(k0 + f * NT, nslots - 1), row = k >> lg, s4 = min(k & (L - 1), Wq - 1);
-                v[f] = src[row * Wq + s4];
-            }
+            for (int f = 0; f < FILL; ++f) v[f] = src[q0 + f * NT];
 #pragma unroll
-            for (int f = 0; f < FILL; ++f) {
-                const int k = k0 + f * NT, s4 = k & (L - 1);
-                if (k < nslots && s4 < Wq) dst[k] = v[f];
-            }
+            for (int f = 0; f < FILL; ++f) dst[slot_of(q0 + f * NT)] = v[f];
         }
+        for (; q0 < nsrc; q0 += NT) dst[slot_of(q0)] = src[q0];
     }
     __syncthreads();
 

@@ -120,6 +120,7 @@ int main(int argc, char *argv[]) {
     Graph *graph;
     Pattern *pattern;
     if (readInput(argv[1], &graph, &pattern, err, sizeof err) != 0) die("bad input", err);
+    double loadedTime = wallSeconds();
 
     int ngpus = gpm_hip_device_count();
     if (ngpus <= 0) die("no GPU found", gpm_hip_last_error());
@@ -137,6 +138,7 @@ int main(int argc, char *argv[]) {
                              sameLists ? NULL : graph->inOffsets, sameLists ? NULL : graph->inEdges,
                              graph->labels) != 0)
         die("graph upload failed", gpm_hip_last_error());
+    double uploadedTime = wallSeconds();
 
     int flags = 0;
     if (sameLists) flags |= PLAN_SYMMETRIC_DATA;
@@ -151,6 +153,7 @@ int main(int argc, char *argv[]) {
     if (buildPlanForGraph(pattern, flags, stats, &plan, err, sizeof err) != 0) die("bad pattern", err);
     graphStatsFree(stats);
     if (gpm_hip_set_plan(ctx, &plan) != 0) die("plan rejected", gpm_hip_last_error());
+    double plannedTime = wallSeconds();
     printf("Distribution time[s]: %d\n", (int)(wallSeconds() - startDistTime));
     fflush(stdout);
 
@@ -170,6 +173,9 @@ int main(int argc, char *argv[]) {
     if (envInt("GPM_STATS", 0)) {
         gpm_stats st;
         gpm_hip_stats(ctx, &st);
+        /* what "Distribution time" is made of: reading the input, GPU set-up + upload + renumbering, planning */
+        fprintf(stderr, "load_s %.3f upload_s %.3f plan_s %.3f\n", loadedTime - startDistTime,
+                uploadedTime - loadedTime, plannedTime - uploadedTime);
         fprintf(stderr, "matches %llu canonical %llu alg_bytes %llu search_ms %.3f tail_ms %.3f extend_ms %.3f\n",
                 (unsigned long long)st.matches, (unsigned long long)st.canonical, (unsigned long long)st.alg_bytes,
                 st.ms_total, st.ms_tail_kernel, st.ms_extend_kernel);

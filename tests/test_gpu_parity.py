@@ -312,7 +312,7 @@ def test_root_shards_sum_to_the_whole():
 
 @pytest.mark.parametrize("pname", ["triangle", "clique4", "cycle4", "diamond", "clique5"])
 def test_mid_size_properties(pname):
-    """R-MAT scale 14: all four device paths agree with each other and with the oracle."""
+    """R-MAT scale 13: all four device paths agree with each other and with the oracle."""
     n, s, d = util.build_graph({"graph": "rmat", "scale": 13, "ef": 8, "seed": 3})
     want = None
     if pname in ("triangle", "clique4"):
@@ -528,9 +528,12 @@ def test_large_universes_of_the_clique_kernel(env, monkeypatch):
     counts = {}
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    # the variant really runs with the matrix it names: 2048 rows (n rounded up to whole words), none, 512
+    want_rows = {"0": 0, "512": 512}.get(env.get("GPM_HUB_ROWS"), 2048)
     for pname in ("triangle", "clique4"):
         m = binding.Matcher(1)
-        m.upload(n, oo, oa)
+        info = m.upload(n, oo, oa)
+        assert info.hub_rows == want_rows, (env, info.hub_rows)
         m.set_pattern(gen.PATTERNS[pname])
         counts[pname] = (m.findMatches(count_only=True), _LARGE_UNIVERSE[pname])
         m.close()
