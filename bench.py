@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+VALU_PEAK_GINSTR = 256 * 2.4  # wave-level vector-ALU instructions per ns: 256 CUs x 1 per clock x 2.4 GHz
 
 
 def log(*a):
@@ -363,7 +364,7 @@ def main():
         if world == 1 and check != total:
             raise SystemExit(f"the accounting search counted {check}, the timed steps {total}")
         matcher.set_accounting(False)
-        if world == 1 and cfg["pattern"].startswith("clique"):
+        if world == 1 and (cfg["pattern"].startswith("clique") or cfg["pattern"] == "triangle"):
             os.environ["GPM_CLIQUE_INFLIGHT"] = "1"
             t1 = time.perf_counter()
             matcher.findMatches(count_only=True)
@@ -376,46 +377,87 @@ def main():
     if rank == 0:
         steps = max(args.steps, 1)
         names = [binding.hip_lib().gpm_hip_kernel_name(k).decode() for k in range(kinds)]
-        # The roofline is quoted on the kernel family with the most device time among those that take their
-        # operands from HBM (k_clq_count4 works on LDS tiles of rows that k_clq_build made: its merge-model
-        # rate says nothing about HBM).  Bytes per step are this rank's share of the accounting search's.
-        dom = max((k for k in range(kinds) if names[k] != "k_clq_count4"), key=lambda k: k_ms[k])
+        # The roofline is quoted on the kernel family with the most device time in the timed steps, whatever
+        # it is.  Bytes per step are this rank's share of the accounting search's.
+        dom = max(range(kinds), key=lambda k: k_ms[k])
         share = 1.0  # of the family's launches of a whole search, the part this rank ran per step
         if world > 1 and not args.no_extra_search:
             share = (k_launches[dom] / steps) / max(int(sb.kernel_launches[dom]), 1)
-        dom_bytes_per_step = k_bytes[dom] * share
-        achieved = (dom_bytes_per_step * steps / 1e9) / (k_ms[dom] / 1e3) if k_ms[dom] > 0 else 0.0
-        traffic, traffic_note, tj = None, "no committed counter pass", {}
+        tj, counters_note = {}, "no committed counter pass"
         # the counter passes are of one GPU running a configuration at its own size: hbm_traffic.json for the
         # headline workload, config<N>_hbm_traffic.json for the others
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json" if args.config == 3 else f"config{args.config}_hbm_traffic.json")
         if overridden or world > 1:
-            traffic_note = "committed counter passes are of the single-GPU run at the configuration's size: not reported"
-        elif os.path.exists(tpath):  # HBM bytes per launch from the committed PMC passes, per kernel family
+            counters_note = "committed counter passes are of the single-GPU run at the configuration's size: not reported"
+        elif os.path.exists(tpath):  # HBM bytes and vector-ALU instructions per launch from the committed PMC passes
             with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("kernels_fingerprint") == kernels_fingerprint():
-                traffic = tj.get(names[dom], {}).get("hbm_bytes_per_launch")
-                traffic_note = f"rocprofv3 counter passes, {tj.get('source', tpath)}"
+                counters_note = (f"committed builder-side rocprofv3 counter passes of these kernel sources "
+                                 f"({tj.get('source', tpath)}); times are this run's HIP events")
             else:
                 tj = {}
-                traffic_note = "committed counter pass is of other kernel sources (stale): not reported"
-        avg_ms = k_ms[dom] / max(k_launches[dom], 1)
-        # the same figures for every family: algorithmic rate (merge model) and, where the committed counter
-        # passes are of these kernel sources, the rate of the bytes HBM really moved per launch
-        families = {}
-        for k in range(kinds):
+                counters_note = "committed counter pass is of other kernel sources (stale): not reported"
+
+        def family(k):
+            """Per launch of family k: time (HIP events; without overlap where the extra search measured it),
+            counter-derived use of the vector ALUs and of HBM, and the merge-model rate as a side figure."""
             if not k_launches[k]:
-                continue
-            fam = {"ms_per_step": k_ms[k] / steps, "launches_per_step": k_launches[k] / steps,
-                   "alg_GB_per_search": k_bytes[k] / 1e9}
-            if k_ms[k] > 0 and k_bytes[k]:
-                fam["alg_GBps"] = (k_bytes[k] * (share if k == dom else 1.0) / 1e9) / (k_ms[k] / steps / 1e3)
-            t = tj.get(names[k], {}).get("hbm_bytes_per_launch")
-            if t is not None and k_ms[k] > 0:
-                fam["hbm_GB_per_launch"] = t / 1e9
-                fam["hbm_GBps"] = (t / 1e9) / (k_ms[k] / k_launches[k] / 1e3)
-            families[names[k]] = fam
+                return None
+            avg_ms = k_ms[k] / k_launches[k]
+            fam = {"ms_per_step": k_ms[k] / steps, "launches_per_step": k_launches[k] / steps, "avg_launch_ms": avg_ms}
+            t_ms, t_from = avg_ms, "timed steps (launches of up to four chunks overlap)" if alone else "timed steps"
+            if alone and alone["kernel_launches"][k]:
+                t_ms = alone["kernel_ms"][k] / alone["kernel_launches"][k]
+                t_from = "extra search with one chunk in flight (launches do not overlap)"
+                fam["avg_launch_ms_alone"] = t_ms
+            fam["rates_over"] = t_from
+            c = tj.get(names[k], {})
+            if c.get("valu_instructions_per_launch") and t_ms > 0:
+                fam["valu_Ginstr_per_launch"] = c["valu_instructions_per_launch"] / 1e9
+                fam["valu_Ginstr_per_s"] = c["valu_instructions_per_launch"] / 1e9 / (t_ms / 1e3)
+                fam["valu_frac"] = fam["valu_Ginstr_per_s"] / VALU_PEAK_GINSTR
+            if c.get("hbm_bytes_per_launch") is not None and t_ms > 0:
+                fam["hbm_GB_per_launch"] = c["hbm_bytes_per_launch"] / 1e9
+                fam["hbm_GBps"] = c["hbm_bytes_per_launch"] / 1e9 / (t_ms / 1e3)
+                fam["hbm_frac"] = fam["hbm_GBps"] / HBM_PEAK_GBS
+            if c.get("lds_conflict_share") is not None:
+                fam["lds_conflict_share"] = c["lds_conflict_share"]
+            if k_bytes[k] and t_ms > 0:  # what streaming every operand list once per partial match would move
+                per_launch = k_bytes[k] * (share if k == dom else 1.0) * steps / k_launches[k]
+                fam["merge_model_GB_per_launch"] = per_launch / 1e9
+                fam["merge_model_GBps"] = per_launch / 1e9 / (t_ms / 1e3)
+                fam["merge_model_frac"] = fam["merge_model_GBps"] / HBM_PEAK_GBS
+            return fam
+
+        families = {names[k]: family(k) for k in range(kinds) if k_launches[k]}
+        fd = families[names[dom]]
+        # which resource binds the dominant family: the larger of its counter-derived shares; without counters
+        # the merge model stands in, as long as it prices the kernel below the HBM peak
+        roof = {"kernel": names[dom], "counters_from": counters_note, "launches": k_launches[dom],
+                "avg_launch_ms": fd.get("avg_launch_ms_alone", fd["avg_launch_ms"]), "rates_over": fd["rates_over"],
+                "traffic": tj.get(names[dom], {}).get("hbm_bytes_per_launch"),
+                "merge_model_frac": fd.get("merge_model_frac"), "merge_model_GBps": fd.get("merge_model_GBps"),
+                "alg_bytes_per_launch": None if "merge_model_GB_per_launch" not in fd else fd["merge_model_GB_per_launch"] * 1e9}
+        if fd.get("valu_frac", 0.0) >= fd.get("hbm_frac", 0.0) and "valu_frac" in fd:
+            roof.update({"bound": "valu", "achieved": fd["valu_Ginstr_per_s"], "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s",
+                         "frac": fd["valu_frac"], "hbm_frac": fd.get("hbm_frac"),
+                         "note": "the family is bound by vector-ALU issue: wave-level VALU instructions per launch "
+                                 "(SQ_INSTS_VALU) over the launch time, against 256 CUs x 1 instruction per clock x "
+                                 "2.4 GHz; hbm_frac is the rate of the bytes HBM really moved (FETCH_SIZE, WRITE_SIZE) "
+                                 "against 8 TB/s; merge_model_frac prices the list streaming the kernel avoids and is "
+                                 "not a utilisation"})
+        elif "hbm_frac" in fd:
+            roof.update({"bound": "hbm", "achieved": fd["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": fd["hbm_frac"], "valu_frac": fd.get("valu_frac"),
+                         "note": "bytes HBM really moved per launch (FETCH_SIZE, WRITE_SIZE, corrected) over the launch "
+                                 "time against 8 TB/s; merge_model_frac is the same time against the algorithmic bytes"})
+        else:
+            mm = fd.get("merge_model_frac")
+            roof.update({"bound": "hbm", "achieved": fd.get("merge_model_GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": mm if mm is not None and mm <= 1.0 else None,
+                         "note": "no counter pass of these kernel sources is committed: merge-model bytes over the launch "
+                                 "time; a model rate above the HBM peak is not a utilisation and is left out"})
         want, want_src = expected_count(args.config, cfg, overridden, labelled)
         if os.environ.get("GPM_EMULATE_RANKS"):  # this process takes every N-th chunk only: a share, not the count
             want, want_src = None, "one emulated rank's share of the chunks (GPM_EMULATE_RANKS): no expected count"
@@ -441,18 +483,7 @@ def main():
             "expected_matches": want,
             "expected_from": want_src,
             "count_ok": None if want is None else bool(total == want),
-            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_from": traffic_note,
-                         "alg_bytes_per_launch": dom_bytes_per_step * steps / max(k_launches[dom], 1),
-                         "avg_launch_ms": avg_ms, "launches": k_launches[dom],
-                         "traffic_GBps": None if traffic is None or avg_ms <= 0 else (traffic / 1e9) / (avg_ms / 1e3),
-                         "traffic_frac": None if traffic is None or avg_ms <= 0 else (traffic / 1e9) / (avg_ms / 1e3) / HBM_PEAK_GBS,
-                         "note": "time: HIP events around every launch of the family inside the timed steps; bytes: "
-                                 "merge-model bytes of the same work, summed on the device in one more search. "
-                                 "frac above 1 means the kernel moves fewer bytes than the merge model streams "
-                                 "(hub-matrix bits and LDS bitmaps instead of list passes); traffic_frac is the "
-                                 "rate of the bytes HBM really moved"},
+            "roofline": roof,
             "kernel_families_rank0": families,
             "whole_search": None if not tj.get("valu_wave_instructions_per_search") or args.config != 3 or overridden else {
                 "note": "all kernels of one search, from the committed counter passes of these kernel sources: "
@@ -463,11 +494,10 @@ def main():
                 "hbm_GB": tj.get("hbm_bytes_per_search", 0.0) / 1e9,
                 "hbm_frac": tj.get("hbm_bytes_per_search", 0.0) / 1e9 / sec_per_step / HBM_PEAK_GBS / world},
             "one_chunk_in_flight": None if alone is None else {
-                "note": "one extra search outside the timed region with launches not overlapping",
-                "ms_per_step": alone["ms_per_step"], "kernel": names[dom],
-                "achieved": (k_bytes[dom] / 1e9) / (alone["kernel_ms"][dom] / 1e3) if alone["kernel_ms"][dom] > 0 else 0.0,
-                "frac": ((k_bytes[dom] / 1e9) / (alone["kernel_ms"][dom] / 1e3) / HBM_PEAK_GBS) if alone["kernel_ms"][dom] > 0 else 0.0,
-                "avg_launch_ms": alone["kernel_ms"][dom] / max(alone["kernel_launches"][dom], 1)},
+                "note": "one extra search outside the timed region with launches not overlapping: family times add up "
+                        "to the search time",
+                "ms_per_step": alone["ms_per_step"],
+                "kernel_ms": {names[k]: alone["kernel_ms"][k] for k in range(kinds) if alone["kernel_launches"][k]}},
             "partial_matches_per_level_rank0": [int(x) for x in list(st.rows_in)[:plan.n_levels]],
             "search_ms_per_step_by_rank": [round(b / steps, 3) for b in busy],
             "chunks_per_step_by_rank": [round(c / steps, 2) for c in taken],

@@ -63,13 +63,14 @@ def _scramble(v: torch.Tensor, bits: int, seed: int) -> torch.Tensor:
     return v
 
 
-def _finish(u: torch.Tensor, v: torch.Tensor, n: int):
-    """Drop self loops, symmetrise, dedupe -> (offsets int64[n+1], adj int32[m])."""
+def _finish(u: torch.Tensor, v: torch.Tensor, n: int, directed: bool = False, multi: bool = False):
+    """Drop self loops, symmetrise, dedupe -> (offsets int64[n+1], adj int32[m]).
+    directed: keep the sampled arcs u -> v as they are (no reverse arcs); multi: keep duplicate arcs."""
     keep = u != v
     u, v = u[keep], v[keep]
-    key = torch.cat([u * n + v, v * n + u])
+    key = u * n + v if directed else torch.cat([u * n + v, v * n + u])
     del u, v
-    key = torch.unique(key)  # sorted ascending
+    key = torch.sort(key).values if multi else torch.unique(key)  # ascending
     src = torch.div(key, n, rounding_mode="floor")
     adj = (key - src * n).to(torch.int32)
     del key
@@ -80,8 +81,9 @@ def _finish(u: torch.Tensor, v: torch.Tensor, n: int):
 
 
 def rmat(scale: int, edge_factor: int, abcd=(0.57, 0.19, 0.19, 0.05), seed: int = 1,
-         device: str | torch.device = "cpu", chunk: int = 1 << 25):
-    """R-MAT graph: 2^scale vertices, edge_factor * 2^scale sampled undirected edges."""
+         device: str | torch.device = "cpu", chunk: int = 1 << 25, directed: bool = False, multi: bool = False):
+    """R-MAT graph: 2^scale vertices, edge_factor * 2^scale sampled edges -- undirected (both arcs listed) unless
+    `directed`, which keeps each sample as the one arc u -> v; `multi` keeps arcs sampled more than once."""
     n = 1 << scale
     m = edge_factor * n
     ta = int(abcd[0] * (1 << 31))
@@ -100,7 +102,7 @@ def rmat(scale: int, edge_factor: int, abcd=(0.57, 0.19, 0.19, 0.05), seed: int 
             v = (v << 1) | vbit
         us.append(_scramble(u, scale, seed))
         vs.append(_scramble(v, scale, seed))
-    return _finish(torch.cat(us), torch.cat(vs), n)
+    return _finish(torch.cat(us), torch.cat(vs), n, directed, multi)
 
 
 def erdos_renyi(n: int, m: int, seed: int = 1, device: str | torch.device = "cpu"):

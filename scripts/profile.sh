@@ -5,13 +5,16 @@
 # gpurun_out/prof_<tag>/ ; scripts/summarize_profile.py turns them into the
 # files kept under profiles/.
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-search"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BENCH > "$OUT/trace.json" 2> "$OUT/trace.err" || exit 1
 echo "trace done"
+# the same with one chunk in flight: launches do not overlap, so a family's time is its own
+GPM_CLIQUE_INFLIGHT=1 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_alone" -o t -- $BENCH > "$OUT/trace_alone.json" 2> "$OUT/trace_alone.err" || exit 1
+echo "trace (one chunk in flight) done"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o t -- $BENCH > "$OUT/fetch.json" 2> "$OUT/fetch.err" || exit 1
 echo "fetch done"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o t -- $BENCH > "$OUT/write.json" 2> "$OUT/write.err" || exit 1

@@ -4,7 +4,7 @@
 # the trace).  Results go to gpurun_out/prof_<tag>_config<N>/ ; scripts/summarize_profile.py <tag>_config<N>
 # turns them into profiles/<tag>_config<N>_* and profiles/config<N>_hbm_traffic.json.
 set -u
-CFG=${1:?configuration number}; TAG=${2:-r2}
+CFG=${1:?configuration number}; TAG=${2:-r3}
 O=gpurun_out/prof_${TAG}_config$CFG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

@@ -65,6 +65,21 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         r["Name"] = short(r["Name"])
         w.writerow(r)
 
+# 1b. the same table from the pass with one chunk in flight (launches do not overlap), when it was made
+alone = {}
+alone_path = os.path.join(src, "trace_alone", "t_kernel_stats.csv")
+if os.path.exists(alone_path):
+    arows = list(csv.DictReader(open(alone_path)))
+    alone = {short(r["Name"]): r for r in arows}
+    with open(os.path.join(dst, f"{tag}_kernel_stats_one_chunk_in_flight.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(arows[0].keys()))
+        w.writeheader()
+        for i, r in enumerate(arows):
+            if i < 12 or short(r["Name"]).startswith(SEARCH):
+                r = dict(r)
+                r["Name"] = short(r["Name"])
+                w.writerow(r)
+
 # 2. counters of the search kernels
 fetch, fcalls = counters("fetch")
 write, _ = counters("write")
@@ -109,9 +124,23 @@ for fam, prefixes in FAMILIES.items():
         continue
     hbm = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in part)
     ms = sum(v["total_ms"] for v in part)
+    valu = sum(v["SQ_INSTS_VALU"] for v in part)
+    conflict, active = sum(v["SQ_LDS_BANK_CONFLICT"] for v in part), sum(v["SQ_LDS_IDX_ACTIVE"] for v in part)
     traffic[fam] = {"launches": calls, "hbm_bytes_total": hbm, "hbm_bytes_per_launch": hbm / calls,
                     "kernel_ms_total": ms, "kernel_avg_ms": ms / calls,
-                    "hbm_GBps_while_running": hbm / 1e9 / (ms / 1e3) if ms else None}
+                    "hbm_GBps_while_running": hbm / 1e9 / (ms / 1e3) if ms else None,
+                    # wave-level vector-ALU instructions (SQ_INSTS_VALU): against 256 CUs x 1 per clock x 2.4 GHz
+                    # over a launch's time this is the share of the issue rate the family uses
+                    "valu_instructions_total": valu, "valu_instructions_per_launch": valu / calls,
+                    "lds_conflict_share": conflict / active if active else None}
+    apart = [v for k, v in alone.items() if k.startswith(prefixes)]
+    acalls = sum(int(v["Calls"]) for v in apart)
+    if acalls:  # launch time without overlap, and the shares of the two peaks that follow from it
+        a_ms = sum(float(v["TotalDurationNs"]) for v in apart) / 1e6
+        traffic[fam]["alone_launches"] = acalls
+        traffic[fam]["alone_avg_ms"] = a_ms / acalls
+        traffic[fam]["valu_frac_alone"] = (valu / calls) / (256 * 2.4e9 * a_ms / acalls / 1e3)
+        traffic[fam]["hbm_frac_alone"] = (hbm / calls) / (8e12 * a_ms / acalls / 1e3)
 # wave-level vector-ALU instructions of all search kernels per search (the profiled command runs 1 warm-up
 # and 2 timed searches): the resource that bounds the clique search once HBM traffic is a third of the
 # merge model's bytes

@@ -49,6 +49,19 @@ SPECS = [
     {"name": "skew10_k6_minus_pm", "graph": "rmat", "scale": 10, "ef": 8, "abcd": [0.7, 0.1, 0.1, 0.1], "seed": 1,
      "pattern": "k6_minus_pm"},
     {"name": "rmat12_ef16_triangle", "graph": "rmat", "scale": 12, "ef": 16, "seed": 1, "pattern": "triangle"},
+    # directed inputs (each sampled arc kept as u -> v, no reverse arc): the in-CSR differs from the out-CSR
+    {"name": "rmatdir12_ef8_tri_dir", "graph": "rmat", "scale": 12, "ef": 8, "seed": 1, "directed": True, "pattern": "tri_dir"},
+    {"name": "rmatdir12_ef8_k4_dag", "graph": "rmat", "scale": 12, "ef": 8, "seed": 1, "directed": True, "pattern": "k4_dag"},
+    {"name": "rmatdir12_ef8_rev4", "graph": "rmat", "scale": 12, "ef": 8, "seed": 1, "directed": True, "pattern": "rev4"},
+    {"name": "rmatdir9_ef8_tree5_dir", "graph": "rmat", "scale": 9, "ef": 8, "seed": 1, "directed": True, "pattern": "tree5_dir"},
+    # a directed multigraph: a quarter of its arcs are listed more than once, and a candidate listed twice is
+    # tried twice (reference: src/gpm-par.c:212-213)
+    {"name": "rmatmulti10_ef16_tri_dir", "graph": "rmat", "scale": 10, "ef": 16, "seed": 1, "directed": True, "multi": True,
+     "pattern": "tri_dir"},
+    {"name": "rmatmulti10_ef16_k4_dag", "graph": "rmat", "scale": 10, "ef": 16, "seed": 1, "directed": True, "multi": True,
+     "pattern": "k4_dag"},
+    {"name": "rmatmulti10_ef16_rev4", "graph": "rmat", "scale": 10, "ef": 16, "seed": 1, "directed": True, "multi": True,
+     "pattern": "rev4"},
     # config 4's twin: 16 labels on the n = 2^14 power-law graph with the full configuration's average degree
     {"name": "plaw14_tree5_labelled16", "graph": "plaw", "n": 1 << 14, "avg_deg": 16, "seed": 1, "pattern": "tree5",
      "labels": 16, "pattern_labels": [0, 1, 2, 3, 1]},

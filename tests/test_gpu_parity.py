@@ -183,6 +183,43 @@ def test_large_goldens(spec, monkeypatch):
         m.close()
 
 
+DIRECTED_LARGE = [g for g in LARGE if g.get("directed")]
+
+
+@pytest.mark.parametrize("spec", DIRECTED_LARGE, ids=[g["name"] for g in DIRECTED_LARGE])
+def test_directed_large_goldens(spec, tmp_path, monkeypatch):
+    """Directed R-MAT graphs of 2^9 .. 2^12 vertices (each sampled arc kept as u -> v only; one of them a
+    multigraph with a quarter of its arcs listed more than once), directed patterns, vectors from the compiled
+    reference: a level reached over an in-edge walks the in-list (reference: src/gpm-par.c:205-206, src/graph.c:7-22),
+    so the context must hold an in-CSR of its own.  Counts with symmetry breaking on and off, in the planner's
+    order and in the reference's; the multiset of rows by checksum through the row sink and, for the smaller
+    vectors, the program's output file."""
+    n, s, d = util.build_graph(spec)
+    pat = gen.PATTERNS[spec["pattern"]]
+    for order in (None, "reference"):
+        if order:
+            monkeypatch.setenv("GPM_PLAN_ORDER", order)
+        m = binding.Matcher(1)
+        info = upload(m, n, s, d)
+        assert not info.symmetric  # in-lists differ from out-lists: a separate in-CSR was uploaded
+        assert bool(info.simple) == (not spec.get("multi"))
+        for symbreak in (True, False):
+            m.set_pattern(pat, symbreak=symbreak)
+            assert m.findMatches(count_only=True) == spec["count"], (spec["name"], order, symbreak)
+        if spec["count"] <= 5_000_000:
+            rows = m.findMatches(count_only=False)
+            assert len(rows) == spec["count"]
+            assert util.rows_multiset_hash(rows) == spec["rows_hash"]
+        m.close()
+    monkeypatch.delenv("GPM_PLAN_ORDER", raising=False)
+    if spec["count"] <= 5_000_000:
+        import io
+        text, _, _ = util.build_input(spec)
+        assert util.md5(text.encode()) == spec["input_md5"]  # the very input the reference was given
+        _, got = run_cli(text, tmp_path)
+        assert util.text_multiset_hash(io.BytesIO(got), pat[0]) == (spec["count"], spec["rows_hash"])
+
+
 def test_labelled_tree_on_the_16_label_twin_through_the_program(tmp_path):
     """Config 4's twin (n = 2^14 power-law graph, 16 labels) through gpm-par.exe: the labels trailer,
     label segments on and off, closed-form leaves on and off."""
@@ -850,7 +887,10 @@ def test_bench_with_two_ranks_from_a_plain_shell(tmp_path):
     assert out["n_gpus"] == 2 and out["matches"] == spec["count"] and out["count_ok"] is True
     assert len(out["search_ms_per_step_by_rank"]) == 2 and len(out["chunks_per_step_by_rank"]) == 2
     assert sum(out["chunks_per_step_by_rank"]) >= 2  # every chunk of a step taken by one of the two ranks
-    assert out["roofline"]["frac"] > 0 and out["scaling"] == "strong"
+    # no counter pass exists for a two-rank run at this size: the line carries the merge-model rate as a side
+    # figure and never a fraction above 1
+    roof = out["roofline"]
+    assert roof["merge_model_frac"] > 0 and (roof["frac"] is None or 0 < roof["frac"] <= 1) and out["scaling"] == "strong"
 
 
 @pytest.mark.parametrize("pname", ["house", "diamond", "cycle4", "k4_dag", "tree5_dir"])

@@ -69,7 +69,7 @@ def build_graph(spec):
         n = spec["n"]
     elif kind == "rmat":
         off, adj = gen.rmat(spec["scale"], spec["ef"], abcd=tuple(spec.get("abcd", (0.57, 0.19, 0.19, 0.05))),
-                            seed=spec["seed"])
+                            seed=spec["seed"], directed=bool(spec.get("directed")), multi=bool(spec.get("multi")))
         n = 1 << spec["scale"]
     elif kind == "plaw":
         off, adj = gen.power_law(spec["n"], avg_deg=spec["avg_deg"], seed=spec["seed"])
