@@ -201,8 +201,12 @@ struct DevState {
     // octahedron path: per-workgroup slabs of masks ((octa_w + 1) words per vertex) and touched lists, root queues
     uint32_t *octa_mask = nullptr;
     int32_t *octa_touched = nullptr;
+    uint32_t *octa_rows = nullptr;   // per slab: the adjacency inside the root's universe, as k_octa_mask leaves it
+    OctaHeader *octa_hdr = nullptr;  // per slab: size of the universe, touched vertices, tasks
     unsigned long long *octa_queue = nullptr;
     int octa_wgs = 0, octa_w = 0;  // octa_wgs = -1: the graph does not fit the kernel (longest N+, memory)
+    int32_t *octa_order = nullptr;  // copy of gpm_ctx::octa_order (roots, heaviest first)
+    uint64_t octa_order_ver = 0;
     std::vector<EventPair> events;
     size_t events_used = 0;
     // results of the last search
@@ -264,6 +268,14 @@ struct gpm_ctx {
                                                 // k_root_cost / two-paths (tests set 1 to cut tiny graphs into many chunks)
     std::vector<Chunk> chunks;
     bool chunks_valid = false;
+    // octahedron path: the roots sorted by estimated work, heaviest first, and the chunk table over that order
+    // (lo, hi are positions in octa_order); empty when the kernel cannot take the graph
+    std::vector<int32_t> octa_order;
+    std::vector<Chunk> octa_chunks;
+    uint64_t octa_order_ver = 0;
+    int octa_streams = 2;  // GPM_OCTA_STREAMS: launches in flight, each on its own stream with its own share of the slabs
+    int octa_seg = 64;  // GPM_OCTA_SEG: touched vertices per task of k_octa_sets for roots with more than 64 higher neighbours
+    int64_t octa_wide_roots = 0;  // GPM_OCTA_WIDE: chunks of at most this many roots build their masks with 16 waves per root (measured: no gain)
     int64_t root_lo = 0, root_hi = 0;
     volatile uint64_t *shared_cursor = nullptr;
     std::atomic<uint64_t> own_cursor{0};
@@ -432,10 +444,17 @@ static void free_graph(DevState &d) {
     dev_free(d.octa_mask);
     dev_free(d.octa_touched);
     dev_free(d.octa_queue);
+    dev_free(d.octa_rows);
+    dev_free(d.octa_hdr);
+    d.octa_rows = nullptr;
+    d.octa_hdr = nullptr;
     d.octa_mask = nullptr;
     d.octa_touched = nullptr;
     d.octa_queue = nullptr;
     d.octa_wgs = d.octa_w = 0;
+    dev_free(d.octa_order);
+    d.octa_order = nullptr;
+    d.octa_order_ver = 0;
     d.cyc_cost = nullptr;
     d.cyc_dense = nullptr;
     d.cyc_queue = nullptr;
@@ -570,6 +589,12 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     ctx->use_clique = env_i64("GPM_NO_CLIQUE", 0) == 0;
     ctx->use_cycle4 = env_i64("GPM_NO_CYCLE4", 0) == 0;
     ctx->use_octa = env_i64("GPM_NO_OCTA", 0) == 0;
+    ctx->octa_streams = (int)std::min<int64_t>(CLQ_INFLIGHT, std::max<int64_t>(1, env_i64("GPM_OCTA_STREAMS", 2)));
+    ctx->octa_wide_roots = env_i64("GPM_OCTA_WIDE", 0);
+    {
+        const int64_t sg = env_i64("GPM_OCTA_SEG", 64);
+        ctx->octa_seg = sg >= 256 ? 256 : sg >= 128 ? 128 : 64;
+    }
     ctx->cyc_rule.heavy_from = std::max<int64_t>(1, env_i64("GPM_CYCLE4_HEAVY", (int64_t)1 << 16));
     ctx->accounting = env_i64("GPM_ACCOUNTING", 1) != 0;
     {
@@ -2209,20 +2234,27 @@ static int ensure_octa(gpm_ctx *ctx, DevState &d) {
     d.octa_wgs = -1;
     if (max_plus > OCTA_MAX_D) return GPM_OK;
     const int W = std::max(1, (max_plus + 31) / 32);
-    const int64_t budget = env_i64("GPM_OCTA_MEM_GB", 16) << 30;
-    const int64_t mask_stride = (W + 2) & ~1;  // as k_octa lays the masks out
+    const int64_t budget = env_i64("GPM_OCTA_MEM_GB", 32) << 30;
+    const int64_t mask_stride = (W + 2) & ~1;  // as the kernels lay the masks out
     const int64_t per_wg = n * (mask_stride + 1) * 4;
-    const int64_t wgs = std::min<int64_t>(env_i64("GPM_OCTA_BLOCKS", 1024), per_wg > 0 ? budget / per_wg : 0);
+    // slabs: one per root of a round
+    const int64_t wgs = std::min<int64_t>(env_i64("GPM_OCTA_BLOCKS", 2048), per_wg > 0 ? budget / per_wg : 0);
     if (wgs < 64) return GPM_OK;
     const size_t mask_bytes = (size_t)wgs * (size_t)n * (size_t)mask_stride * sizeof(uint32_t);
+    const size_t rows_bytes = (size_t)wgs * (size_t)(32 * W) * (size_t)OCTA_ROW_WORDS(W) * sizeof(uint32_t);
     if (hipMalloc(&d.octa_mask, mask_bytes) != hipSuccess || hipMalloc(&d.octa_touched, (size_t)wgs * (size_t)n * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&d.octa_rows, rows_bytes) != hipSuccess || hipMalloc(&d.octa_hdr, (size_t)wgs * sizeof(OctaHeader)) != hipSuccess ||
         hipMalloc(&d.octa_queue, 1024 * sizeof(unsigned long long)) != hipSuccess) {
         (void)hipGetLastError();
         dev_free(d.octa_mask);
         dev_free(d.octa_touched);
+        dev_free(d.octa_rows);
+        dev_free(d.octa_hdr);
         dev_free(d.octa_queue);
         d.octa_mask = nullptr;
         d.octa_touched = nullptr;
+        d.octa_rows = nullptr;
+        d.octa_hdr = nullptr;
         d.octa_queue = nullptr;
         return GPM_OK;
     }
@@ -2306,6 +2338,8 @@ static int prepare_chunks(gpm_ctx *ctx) {
     int64_t want = ctx->chunk_hint > 0 ? ctx->chunk_hint : 32 * (int64_t)ctx->devs.size();
     // The two-path counts are exact costs and every chunk is one persistent launch: few, large chunks.  Several
     // processes on one cursor need chunks to steal from each other, so there the count is only halved.
+    // chunks of the octahedron path (its own table, below): launches overlap on streams, a quarter of the hint
+    const int64_t want_octa = std::max<int64_t>(1, want / 4);
     if (cyc || (ctx->octa && ctx->use_octa)) want = std::max<int64_t>(1, want / (ctx->shared_cursor ? 2 : 8));
     // the level-by-level path synchronises with the host several times per chunk: fewer, larger chunks
     else if (!(ctx->clique_k && ctx->use_clique)) want = std::max<int64_t>(1, want / 8);
@@ -2324,6 +2358,70 @@ static int prepare_chunks(gpm_ctx *ctx) {
         c.hi = lo + end;
         ctx->chunks.push_back(c);
         begin = end;
+    }
+    // Octahedra: one workgroup works through a root, and the heaviest roots take milliseconds.  The roots are
+    // therefore sorted by estimated work, heaviest first, and the chunks are ranges of that order: a launch
+    // begins with its longest roots and ends with its shortest, so its tail is short, and launches of several
+    // chunks overlap on streams of their own.
+    ctx->octa_order.clear();
+    ctx->octa_chunks.clear();
+    ctx->octa_order_ver++;
+    if (ctx->octa && ctx->use_octa) {
+        bool fits = true;
+        for (auto &dv : ctx->devs) {
+            int orc = ensure_octa(ctx, dv);
+            if (orc) return orc;
+            fits = fits && dv.octa_wgs > 0;
+        }
+        HIP_TRY(hipSetDevice(d.dev));
+        if (fits) {
+            Scratch k1, k2, v1, v2, tmp, pf;
+            HIP_TRY(k1.alloc((size_t)nroots * sizeof(uint64_t)));
+            HIP_TRY(k2.alloc((size_t)nroots * sizeof(uint64_t)));
+            HIP_TRY(v1.alloc((size_t)nroots * sizeof(int32_t)));
+            HIP_TRY(v2.alloc((size_t)nroots * sizeof(int32_t)));
+            HIP_TRY(pf.alloc((size_t)nroots * sizeof(uint64_t)));
+            k_octa_cost<<<grid_for(nroots), 256, 0, s>>>(d.gv, lo, hi, k1.as<uint64_t>(), v1.as<int32_t>());
+            HIP_TRY(hipGetLastError());
+            size_t bytes = 0;
+            HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, bytes, k1.as<uint64_t>(), k2.as<uint64_t>(), v1.as<int32_t>(),
+                                                   v2.as<int32_t>(), (size_t)nroots, 0u, 64u, s));
+            HIP_TRY(tmp.alloc(bytes));
+            HIP_TRY(rocprim::radix_sort_pairs_desc(tmp.p, bytes, k1.as<uint64_t>(), k2.as<uint64_t>(), v1.as<int32_t>(),
+                                                   v2.as<int32_t>(), (size_t)nroots, 0u, 64u, s));
+            bytes = 0;
+            HIP_TRY(rocprim::inclusive_scan(nullptr, bytes, k2.as<uint64_t>(), pf.as<uint64_t>(), (size_t)nroots,
+                                            rocprim::plus<uint64_t>(), s));
+            HIP_TRY(tmp.alloc(bytes));
+            HIP_TRY(rocprim::inclusive_scan(tmp.p, bytes, k2.as<uint64_t>(), pf.as<uint64_t>(), (size_t)nroots,
+                                            rocprim::plus<uint64_t>(), s));
+            std::vector<uint64_t> opref((size_t)nroots);
+            ctx->octa_order.resize((size_t)nroots);
+            HIP_TRY(hipMemcpyAsync(opref.data(), pf.p, (size_t)nroots * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(ctx->octa_order.data(), v2.p, (size_t)nroots * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            // roots with fewer than four higher neighbours hold no copy (estimate 1): the order ends before them
+            int64_t active = nroots;
+            while (active > 0 && opref[(size_t)active - 1] - (active > 1 ? opref[(size_t)active - 2] : 0) <= 1) --active;
+            opref.resize((size_t)active);
+            ctx->octa_order.resize((size_t)std::max<int64_t>(active, 1));
+            if (active == 0) {  // one empty chunk keeps the table in use
+                Chunk c{};
+                ctx->octa_chunks.push_back(c);
+            }
+            const uint64_t per_chunk = std::max<uint64_t>(1, (active ? opref.back() : 1) / (uint64_t)want_octa);
+            int64_t ob = 0;
+            while (ob < active) {
+                const uint64_t base = ob ? opref[(size_t)ob - 1] : 0;
+                int64_t oe = std::lower_bound(opref.begin() + ob, opref.end(), base + per_chunk) - opref.begin() + 1;
+                oe = std::min(oe, active);
+                Chunk c{};
+                c.lo = ob;
+                c.hi = oe;
+                ctx->octa_chunks.push_back(c);
+                ob = oe;
+            }
+        }
     }
     if (ctx->clique_k && ctx->use_clique) {
         const int nch = (int)ctx->chunks.size();
@@ -2382,15 +2480,23 @@ static int device_search(const SearchArgs &a, DevState &d) {
     const bool clique = a.count_only && ctx->clique_k >= 3 && ctx->use_clique && !a.fixed_memory;
     if (clique) HIP_TRY(hipMemsetAsync(d.clq_slots, 0, GPM_KERNEL_KINDS * CLQ_SLOTS * sizeof(unsigned long long), s));
     HIP_TRY(hipStreamSynchronize(s));  // counters are zero before any slot stream adds to them
-    bool octa = a.count_only && ctx->octa && ctx->use_octa && !a.fixed_memory;
+    // the octahedron kernel runs when every device of the context could take the graph (prepare_chunks then
+    // made the sorted root order and its chunk table)
+    const bool octa = a.count_only && ctx->octa && ctx->use_octa && !a.fixed_memory && !ctx->octa_chunks.empty() &&
+                      d.octa_wgs > 0;
     if (octa) {
-        if ((rc = ensure_octa(ctx, d))) return rc;
-        octa = d.octa_wgs > 0;
-        if (octa) {
-            HIP_TRY(hipMemsetAsync(d.octa_queue, 0, 1024 * sizeof(unsigned long long), s));
-            HIP_TRY(hipStreamSynchronize(s));
+        if (d.octa_order_ver != ctx->octa_order_ver) {
+            dev_free(d.octa_order);
+            d.octa_order = nullptr;
+            HIP_TRY(hipMalloc(&d.octa_order, ctx->octa_order.size() * sizeof(int32_t)));
+            HIP_TRY(hipMemcpyAsync(d.octa_order, ctx->octa_order.data(), ctx->octa_order.size() * sizeof(int32_t),
+                                   hipMemcpyHostToDevice, s));
+            d.octa_order_ver = ctx->octa_order_ver;
         }
+        HIP_TRY(hipMemsetAsync(d.octa_queue, 0, 1024 * sizeof(unsigned long long), s));
+        HIP_TRY(hipStreamSynchronize(s));
     }
+    const std::vector<Chunk> &table = octa ? ctx->octa_chunks : ctx->chunks;
     const bool cyc = a.count_only && ctx->cycle4 && ctx->use_cycle4 && !a.fixed_memory;
     if (cyc) {
         if ((rc = ensure_cycle4(ctx, d))) return rc;
@@ -2405,7 +2511,7 @@ static int device_search(const SearchArgs &a, DevState &d) {
         HIP_TRY(hipMemsetAsync(d.cyc_queue, 0, 1024 * sizeof(unsigned long long), s));
         HIP_TRY(hipStreamSynchronize(s));
     }
-    uint64_t seq = 0, cyc_heavy_seq = 0;
+    uint64_t seq = 0, cyc_heavy_seq = 0, octa_rounds = 0;
     // chunks in flight on the clique path; 1 runs every launch with the GPU to itself (kernel times
     // then add up to the wall time, which is how a kernel's own rate is measured)
     const int clq_inflight = (int)std::min<int64_t>(CLQ_INFLIGHT, std::max<int64_t>(1, env_i64("GPM_CLIQUE_INFLIGHT", CLQ_INFLIGHT)));
@@ -2423,28 +2529,64 @@ static int device_search(const SearchArgs &a, DevState &d) {
             if (fixed_chunk.lo >= ctx->root_hi) break;
         } else {
             c = claim_chunk(ctx);
-            if (c >= ctx->chunks.size()) break;
+            if (c >= table.size()) break;
         }
-        const Chunk &ch = a.fixed_memory ? fixed_chunk : ctx->chunks[(size_t)c];
+        const Chunk &ch = a.fixed_memory ? fixed_chunk : table[(size_t)c];
         const int64_t lo = ch.lo, hi = ch.hi;
         d.chunks++;
         if (octa) {
-            // one launch per chunk on the main stream: the workgroups take the chunk's roots from a queue
-            // and share nothing but that; launches follow each other (the slabs belong to workgroup numbers)
-            if (seq && seq % 1024 == 0) {
-                HIP_TRY(hipStreamSynchronize(s));
-                HIP_TRY(hipMemsetAsync(d.octa_queue, 0, 1024 * sizeof(unsigned long long), s));
+            // A chunk is a range of the sorted root order, worked off in rounds of as many roots as its
+            // stream has slabs: k_octa_mask builds the masks of a round's roots, k_octa_sets counts over their
+            // touched vertices.  Chunks alternate over octa_streams streams, each with its own share of the
+            // slabs, so the rounds of several chunks overlap.
+            const int groups = std::max(1, std::min(ctx->octa_streams, d.octa_wgs / 64));
+            const int slabs = std::min(1024, d.octa_wgs / groups);
+            const int grp = (int)(seq % (uint64_t)groups);
+            ChunkSlot &sl = d.slots[grp];
+            if (sl.busy) {  // at most `groups` chunks ahead of the GPU: what is not claimed yet is left for other ranks to take
+                HIP_TRY(hipEventSynchronize(sl.done));
+                sl.busy = false;
             }
+            hipStream_t os = sl.stream;
+            const size_t mask_stride = (size_t)((d.octa_w + 2) & ~1);
+            uint32_t *gmask = d.octa_mask + (size_t)grp * (size_t)slabs * (size_t)d.n * mask_stride;
+            int32_t *gtouched = d.octa_touched + (size_t)grp * (size_t)slabs * (size_t)d.n;
+            uint32_t *grows = d.octa_rows + (size_t)grp * (size_t)slabs * (size_t)(32 * d.octa_w) * (size_t)OCTA_ROW_WORDS(d.octa_w);
+            OctaHeader *ghdr = d.octa_hdr + (size_t)grp * (size_t)slabs;
             d.rows_in[0] += (uint64_t)(hi - lo);
-            if ((rc = timed_begin(d, GPM_KIND_OCTA, hi - lo, s))) return rc;
-            k_octa<<<(unsigned)d.octa_wgs, 256, OCTA_LDS_BYTES(d.octa_w), s>>>(d.gv, lo, hi, d.octa_queue + seq % 1024, d.octa_mask,
-                                                                              d.octa_touched, d.octa_w, d.ctr + CTR_TAIL_MATCHES,
-                                                                              d.ctr + CTR_OCTA_BYTES);
-            HIP_TRY(hipGetLastError());
-            if ((rc = timed_end(d, s))) return rc;
+            // a chunk of few roots is a chunk of heavy roots (chunks hold equal estimated work): 16 waves walk
+            // the lists of such a root's members
+            const bool wide = hi - lo <= ctx->octa_wide_roots;
+            const unsigned sets_wgs = (unsigned)std::max(256, 2048 / groups);
+            for (int64_t base = lo; base < hi; base += slabs) {
+                const int64_t nr = std::min<int64_t>(slabs, hi - base);
+                if (octa_rounds && octa_rounds % 1024 == 0) {  // the queue words are used up: all rounds done, then zeroed
+                    for (auto &x : d.slots) HIP_TRY(hipStreamSynchronize(x.stream));
+                    HIP_TRY(hipMemsetAsync(d.octa_queue, 0, 1024 * sizeof(unsigned long long), s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                }
+                unsigned long long *q = d.octa_queue + octa_rounds % 1024;
+                octa_rounds++;
+                if ((rc = timed_begin(d, GPM_KIND_OCTA, nr, os, wide ? 16 : 4))) return rc;
+                if (wide)
+                    k_octa_mask<16><<<(unsigned)nr, 16 * GPM_WAVE, OCTA_MASK_LDS_BYTES(d.octa_w), os>>>(
+                        d.gv, d.octa_order, base, base + nr, gmask, gtouched, grows, ghdr, d.octa_w, ctx->octa_seg, d.ctr + CTR_OCTA_BYTES);
+                else
+                    k_octa_mask<4><<<(unsigned)nr, 4 * GPM_WAVE, OCTA_MASK_LDS_BYTES(d.octa_w), os>>>(
+                        d.gv, d.octa_order, base, base + nr, gmask, gtouched, grows, ghdr, d.octa_w, ctx->octa_seg, d.ctr + CTR_OCTA_BYTES);
+                HIP_TRY(hipGetLastError());
+                if ((rc = timed_end(d, os))) return rc;
+                if ((rc = timed_begin(d, GPM_KIND_OCTA, nr, os, 1))) return rc;  // tag 1: the sets kernel
+                k_octa_sets<<<sets_wgs, 256, OCTA_SETS_LDS_BYTES(d.octa_w, ctx->octa_seg), os>>>(d.gv, (int)nr, ghdr, gmask, gtouched, grows,
+                                                                                 d.octa_w, q, d.ctr + CTR_TAIL_MATCHES);
+                HIP_TRY(hipGetLastError());
+                if ((rc = timed_end(d, os))) return rc;
+            }
+            HIP_TRY(hipEventRecord(sl.done, os));
+            sl.busy = true;
             seq++;
             if (d.events_used > 4096) {
-                HIP_TRY(hipStreamSynchronize(s));
+                for (auto &x : d.slots) HIP_TRY(hipStreamSynchronize(x.stream));
                 if ((rc = collect_times(d, ctx->trace))) return rc;
             }
             continue;
@@ -2581,8 +2723,11 @@ static int device_search(const SearchArgs &a, DevState &d) {
     if (ctx->trace)
         fprintf(stderr, "gpm trace: all chunks enqueued %.3f ms after the search began\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
-    if (cyc)
-        for (auto &x : d.slots) HIP_TRY(hipStreamSynchronize(x.stream));
+    if (cyc || octa)
+        for (auto &x : d.slots) {
+            HIP_TRY(hipStreamSynchronize(x.stream));
+            x.busy = false;
+        }
     if (clique) {
         for (auto &x : d.slots) {
             HIP_TRY(hipStreamSynchronize(x.stream));

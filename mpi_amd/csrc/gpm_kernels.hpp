@@ -2652,175 +2652,330 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
 // induces: half the sum over pairs {x, y} of T of c(c-1)/2, c = |N(x) ^ N(y) ^ T|.  Each copy stands for 48
 // embeddings (the reference reports every automorphic image, reference: src/gpm-par.c:179-243).
 //
-// One workgroup per root u, roots taken from a queue.  Every vertex t above u gets a bit mask over the
-// positions of U: the members of U adjacent to t.  The masks live in a slab of global memory that belongs
-// to the workgroup (room for W + 1 words per vertex of the graph, rounded up to an even number, all zero between
-// roots; a root uses only as many words per vertex as its own universe needs): the waves walk the lists
-// of U's members above u and OR the member's bit into the mask of every entry (atomics in L2; word W of a
-// mask says which of its words hold bits, and who finds it empty appends the vertex to the workgroup's list
-// of touched vertices).  The
-// masks of U's own members are the adjacency inside U, both directions: they are copied to LDS as rows.  Then
-// every touched vertex t with at least four bits is a u': a wave lists the members of its mask and its lanes
-// take the pairs {x, y}, three-way AND of two LDS rows and the mask.  Masks are cleared as they are used.
+// Two kernels per round of roots, each root with a slab of global memory of its own for the round.
+//
+// k_octa_mask: one workgroup per root u.  Every vertex t above u gets a bit mask over the positions of U:
+// the members of U adjacent to t.  The masks live in the root's slab (room for W + 1 words per vertex of the
+// graph, rounded up to an even number, all zero between rounds; a root uses only as many words per vertex as
+// its own universe needs): the waves walk the lists of U's members above u and OR the member's bit into the
+// mask of every entry (atomics in L2; word Wd of a mask says which of its words hold bits, and who finds it
+// empty appends the vertex to the slab's list of touched vertices).  The masks of U's own members are the
+// adjacency inside U, both directions: they are copied out as rows, and a header records the universe's size
+// and the number of touched vertices.
+//
+// k_octa_sets: the touched vertices of all roots of the round, cut into tasks of 64 or 256 vertices that
+// persistent workgroups take from a queue -- a root with 10^5 touched vertices is spread over the whole GPU
+// instead of keeping one workgroup busy for milliseconds.  A task copies its root's rows to LDS; every
+// touched vertex t with at least four bits is a u': a wave lists the members of its mask and its lanes take
+// the pairs {x, y}, three-way AND of two LDS rows and the mask.  Masks are cleared as they are read, so the
+// slab is all zero again when the round ends.
 // Universes of up to OCTA_MAX_D vertices; the caller checks the longest N+ and the memory for the slabs.
-// Dynamic LDS (words), D = 32 W (the graph's longest N+ rounded up), Wr = W rounded up to 4:
-// U[D] | rows[D * Wr] | per wave: members[D / 2] (16-bit).
 #define OCTA_MAX_D 512
+#define OCTA_MLP 8     // mask bits set per lane and trip
 #define OCTA_ROW_WORDS(W) (((W) + 3) & ~3)  // rows are read 16 bytes at a time
-#define OCTA_LDS_BYTES(W) ((32 * (W) + 32 * (W) * OCTA_ROW_WORDS(W) + 4 * (32 * (W) / 2)) * 4)
+// dynamic LDS: k_octa_mask U[D] | list begins[D] (64-bit) | list lengths[D]; k_octa_sets rows[D * Wr] | per wave: members[D / 2] (16-bit) | sets[OCTA_SETS_WORDS(W, seg_wide)];
+// D = 32 W, Wr = W rounded up to 4
+#define OCTA_MASK_LDS_BYTES(W) (4 * 32 * (W) * 4)
+// room for the sets of one task: SEGW wide ones (universes above 64 vertices) or 256 of up to two words
+#define OCTA_SETS_WORDS(W, SEGW) ((SEGW) * ((W) + 1) > 768 ? (SEGW) * ((W) + 1) : 768)
+#define OCTA_SETS_LDS_BYTES(W, SEGW) ((32 * (W) * OCTA_ROW_WORDS(W) + 4 * (32 * (W) / 2) + OCTA_SETS_WORDS(W, SEGW)) * 4)
 
-__global__ __launch_bounds__(256) void k_octa(GraphView g, int64_t lo, int64_t hi, unsigned long long *queue,
-                                              uint32_t *mask_all, int32_t *touched_all, int W,
-                                              unsigned long long *n_copies, unsigned long long *alg_bytes) {
+// What k_octa_mask leaves for k_octa_sets about the root of one slab.
+struct OctaHeader {
+    int32_t d;       // size of the universe, 0: nothing to do
+    int32_t nt;      // touched vertices
+    int32_t seg;     // touched vertices per task of k_octa_sets: 64 for wide universes (large sets), else 256
+    int32_t ntasks;  // ceil(nt / seg)
+};
+
+// Layout of one root's masks and rows, from the size of its universe.
+struct OctaGeom {
+    int Wd, Wrd, rstride;
+    bool one_word, half_word;
+};
+__device__ __forceinline__ OctaGeom octa_geom(int d) {
+    OctaGeom q;
+    q.Wd = (d + 31) >> 5;
+    q.Wrd = OCTA_ROW_WORDS(q.Wd);
+    q.one_word = d <= 64;   // one 64-bit word per mask: the word itself tells the first setter
+    q.half_word = d <= 32;  // one 32-bit word: twice as many masks to a cache line again
+    // a root's masks are as wide as its universe and lie that close together in the slab: the narrower, the
+    // more of them share a cache line
+    q.rstride = q.half_word ? 1 : q.one_word ? 2 : (q.Wd + 2) & ~1;
+    return q;
+}
+
+// grid = roots of the round (at most the slabs of the launch's group); NW waves per workgroup.
+template <int NW>
+__global__ __launch_bounds__(NW * GPM_WAVE) void k_octa_mask(GraphView g, const int32_t *order, int64_t lo, int64_t hi,
+                                                             uint32_t *mask_all, int32_t *touched_all, uint32_t *rows_all,
+                                                             OctaHeader *hdr, int W, int seg_wide,
+                                                             unsigned long long *alg_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    __shared__ long long s_root;
     __shared__ int s_nt;
+    constexpr int NT = NW * GPM_WAVE;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
+    const int64_t ri = lo + blockIdx.x;
+    if (ri >= hi) return;
     int32_t *U = (int32_t *)smem;
-    const int Dcap = 32 * W, Wr = OCTA_ROW_WORDS(W);
-    uint32_t *rows = smem + Dcap;
-    uint16_t *members = (uint16_t *)(smem + Dcap + Dcap * Wr + wave * (Dcap / 2));
     const int stride = (W + 2) & ~1;  // even: the first two words of a mask are also one 64-bit word
     uint32_t *mask = mask_all + (size_t)blockIdx.x * (size_t)g.n * (size_t)stride;
     int32_t *touched = touched_all + (size_t)blockIdx.x * (size_t)g.n;
+    uint32_t *rows_g = rows_all + (size_t)blockIdx.x * (size_t)(32 * W) * (size_t)OCTA_ROW_WORDS(W);
     const int64_t *off = g.off[0], *mid = g.mid[0];
     const int32_t *adj = g.adj[0];
+    const int32_t u = order[ri];  // roots in the order of their estimated work, heaviest first
+    const int64_t ub = mid[u];
+    const int d = (int)(off[u + 1] - ub);
+    if (d < 4) {
+        if (tid == 0) hdr[blockIdx.x] = OctaHeader{0, 0, 64, 0};
+        return;
+    }
+    if (tid == 0) s_nt = 0;
+    // the part of every member's list above u, found by all threads at once (one member each): a wave that
+    // searched for the lists of its members one after the other waited for a chain of a dozen loads per member
+    int64_t *Lb = reinterpret_cast<int64_t *>(smem + 32 * W);
+    int32_t *Ln = (int32_t *)(smem + 32 * W + 2 * 32 * W);
+    for (int x = tid; x < d; x += NT) {
+        const int32_t mvert = adj[ub + x];
+        U[x] = mvert;
+        const int64_t e = off[mvert + 1];
+        const int64_t b = lower_bound_g(adj, off[mvert], e, u + 1);
+        Lb[x] = b;
+        Ln[x] = (int32_t)(e - b);
+    }
+    const OctaGeom q = octa_geom(d);
+    const int Wd = q.Wd, rstride = q.rstride;
     uint64_t bytes = 0;  // the root, its higher neighbours and every list entry walked, 4 each
+    __syncthreads();
+    // masks: member x sets its bit in the mask of every neighbour above u (lists ascend: entered above u)
+    for (int x = wave; x < d; x += NW) {
+        const int64_t b = Lb[x], e = b + Ln[x];
+        const uint32_t bit = 1u << (x & 31);
+        if (lane == 0) bytes += 4ull * (uint64_t)(e - b) + 4ull + (x == 0 ? 4ull : 0ull);
+        // OCTA_MLP entries per lane and trip: their atomics are all issued before the first old value is
+        // looked at (an atomic that returns a value costs a round trip to the L2)
+        for (int64_t p0 = b; p0 < e; p0 += OCTA_MLP * GPM_WAVE) {
+            int32_t t[OCTA_MLP];
+            uint32_t old[OCTA_MLP];
+#pragma unroll
+            for (int k = 0; k < OCTA_MLP; ++k) {
+                const int64_t p = p0 + k * GPM_WAVE + lane;
+                t[k] = p < e ? adj[p] : -1;
+            }
+            if (q.half_word) {
+#pragma unroll
+                for (int k = 0; k < OCTA_MLP; ++k) old[k] = t[k] >= 0 ? atomicOr(mask + (size_t)t[k], bit) : 1u;
+            } else if (q.one_word) {
+#pragma unroll
+                for (int k = 0; k < OCTA_MLP; ++k)
+                    old[k] = t[k] >= 0 ? (atomicOr(reinterpret_cast<unsigned long long *>(mask + 2 * (size_t)t[k]), 1ull << x) != 0ull) : 1u;
+            } else {
+#pragma unroll
+                for (int k = 0; k < OCTA_MLP; ++k)
+                    old[k] = t[k] >= 0 ? atomicOr(mask + (size_t)t[k] * (size_t)rstride + (x >> 5), bit) : 1u;
+#pragma unroll
+                for (int k = 0; k < OCTA_MLP; ++k)
+                    if (old[k] == 0u) old[k] = atomicOr(mask + (size_t)t[k] * (size_t)rstride + Wd, 1u << (x >> 5));
+            }
+#pragma unroll
+            for (int k = 0; k < OCTA_MLP; ++k)
+                if (old[k] == 0u) touched[atomicAdd(&s_nt, 1)] = t[k];
+        }
+    }
+    __syncthreads();
+    // the masks of U's members are the adjacency inside U (read past the L1: they were written by atomics)
+    for (int x = tid; x < d * q.Wrd; x += NT) {
+        const int i = x / q.Wrd, w = x - i * q.Wrd;
+        rows_g[x] = w < Wd ? __hip_atomic_load(mask + (size_t)U[i] * (size_t)rstride + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+    if (tid == 0) {
+        const int seg = d > 64 ? seg_wide : 256;  // the sets kernel is launched with LDS for seg_wide wide sets
+        hdr[blockIdx.x] = OctaHeader{d, s_nt, seg, (s_nt + seg - 1) / seg};
+    }
+    bytes = wave_sum_u64(bytes);
+    if (lane == 0 && bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
+}
+
+// Persistent workgroups of four waves; nslabs = roots of the round.  LDS (static): the running task counts of
+// the round's roots.
+__global__ __launch_bounds__(256) void k_octa_sets(GraphView g, int nslabs, const OctaHeader *hdr, uint32_t *mask_all,
+                                                   const int32_t *touched_all, const uint32_t *rows_all, int W,
+                                                   unsigned long long *queue, unsigned long long *n_copies) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ int s_first[1025];  // tasks of the slabs before slab i (nslabs <= 1024)
+    __shared__ int s_task;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
+    const int Dcap = 32 * W, Wr = OCTA_ROW_WORDS(W);
+    uint32_t *rows = smem;
+    uint16_t *members = (uint16_t *)(smem + Dcap * Wr + wave * (Dcap / 2));
+    uint32_t *sets = smem + Dcap * Wr + 4 * (Dcap / 2);  // masks (and sizes) of the task's vertices with four bits or more
+    __shared__ int s_nsets;
+    const int stride = (W + 2) & ~1;
+    {  // exclusive prefix of the task counts: every thread sums a run of four slabs, the runs are scanned
+        int mine[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mine[k] = 4 * tid + k < nslabs ? hdr[4 * tid + k].ntasks : 0;
+            sum += mine[k];
+        }
+        __shared__ int s_wave[4];
+        int incl = sum;
+        for (int o = 1; o < GPM_WAVE; o <<= 1) {
+            const int up = __shfl_up(incl, o, GPM_WAVE);
+            if (lane >= o) incl += up;
+        }
+        if (lane == GPM_WAVE - 1) s_wave[wave] = incl;
+        __syncthreads();
+        int before = incl - sum;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s_first[4 * tid + k] = before;
+            before += mine[k];
+        }
+        if (tid == 255) s_first[1024] = before;
+    }
+    __syncthreads();
+    const int ntasks = s_first[1024];
     // Every 4-cycle of a set T is found at both of its diagonals: the lanes add what their pairs find, and
     // the sum over the wave -- whole sets only, so an even number -- is halved at the end.
     uint64_t twice = 0;
+    int have = -1;  // slab whose rows are in LDS
     for (;;) {
-        __syncthreads();  // the last root is done with s_root, s_nt and the LDS rows
-        if (tid == 0) {
-            s_root = (long long)(lo + (int64_t)atomicAdd(queue, 1ull));
-            s_nt = 0;
-        }
+        __syncthreads();  // the last task is done with s_task and the LDS rows
+        if (tid == 0) s_task = (int)atomicAdd(queue, 1ull);
         __syncthreads();
-        const int64_t ri = s_root;
-        if (ri >= hi) break;
-        const int32_t u = (int32_t)(g.n - 1 - ri);
-        const int64_t ub = mid[u];
-        const int d = (int)(off[u + 1] - ub);
-        if (d < 4) continue;
-        for (int x = tid; x < d; x += 256) U[x] = adj[ub + x];
-        const bool one_word = d <= 64;
-        // This root's masks are as wide as its universe (Wd words and the flag word, none for one 64-bit
-        // word) and lie that close together in the slab: the narrower, the more of them share a cache line.
-        // The slab is all zero between roots, so every root may lay it out anew.
-        const int Wd = (d + 31) >> 5;
-        const int Wrd = OCTA_ROW_WORDS(Wd), Wqd = Wrd / 4;  // the LDS rows are as wide as the universe, too
+        const int task = s_task;
+        if (task >= ntasks) break;
+        int slab = 0;  // last slab whose first task is <= task and that has tasks
+        for (int b = 512; b > 0; b >>= 1)
+            if (slab + b < 1024 && s_first[slab + b] <= task) slab += b;
+        const int seg = task - s_first[slab];
+        const OctaHeader h = hdr[slab];
+        const int d = h.d, nt = h.nt;
+        const OctaGeom q = octa_geom(d);
+        const int Wd = q.Wd, Wrd = q.Wrd, Wqd = Wrd / 4, rstride = q.rstride;
+        const bool one_word = q.one_word, half_word = q.half_word;
         // rows lie an odd number of 16-byte pieces apart where that fits: piece v of rows r and r + 8 would
         // share its banks at a stride of 8 words
         const int Wsd = (Wrd | 4) * d <= Dcap * Wr ? (Wrd | 4) : Wrd;
-        const bool half_word = d <= 32;  // one 32-bit word: twice as many masks to a cache line again
-        const int rstride = half_word ? 1 : one_word ? 2 : (Wd + 2) & ~1;
-        __syncthreads();
-        // masks: member x sets its bit in the mask of every neighbour above u (lists ascend: entered above u)
-        for (int x = wave; x < d; x += 4) {
-            const int32_t mvert = U[x];
-            const int64_t e = off[mvert + 1];
-            const int64_t b = lower_bound_g(adj, off[mvert], e, u + 1);
-            const uint32_t bit = 1u << (x & 31);
-            if (lane == 0) bytes += 4ull * (uint64_t)(e - b) + 4ull + (x == 0 ? 4ull : 0ull);
-            for (int64_t p = b + lane; p < e; p += GPM_WAVE) {
-                const int32_t t = adj[p];
-                uint32_t *mt = mask + (size_t)t * (size_t)rstride;
-                // word Wd of a mask says which of its words hold bits; who finds it empty lists the vertex.  A
-                // universe of at most 64 vertices has masks of one 64-bit word: the word itself tells.
-                bool first;
-                if (half_word) first = atomicOr(mt, bit) == 0u;
-                else if (one_word) first = atomicOr(reinterpret_cast<unsigned long long *>(mt), 1ull << x) == 0ull;
-                else first = atomicOr(mt + (x >> 5), bit) == 0u && atomicOr(mt + Wd, 1u << (x >> 5)) == 0u;
-                if (first) touched[atomicAdd(&s_nt, 1)] = t;
+        uint32_t *mask = mask_all + (size_t)slab * (size_t)g.n * (size_t)stride;
+        const int32_t *touched = touched_all + (size_t)slab * (size_t)g.n;
+        if (slab != have) {
+            const uint32_t *rows_g = rows_all + (size_t)slab * (size_t)Dcap * (size_t)Wr;
+            for (int x = tid; x < d * Wrd; x += 256) {
+                const int i = x / Wrd, w = x - i * Wrd;
+                rows[i * Wsd + w] = rows_g[x];
             }
+            have = slab;
+            __syncthreads();
         }
+        // Most touched vertices are adjacent to fewer than four members.  Every thread takes one touched vertex
+        // of the task: it reads and clears the mask of its vertex (the reads of all masks are in flight
+        // together) and counts its bits; the masks with at least four bits go to a list in LDS.
+        if (tid == 0) s_nsets = 0;
         __syncthreads();
-        const int nt = s_nt;
-        // the masks of U's members are the adjacency inside U (read past the L1: they were written by atomics)
-        for (int x = tid; x < d * Wrd; x += 256) {
-            const int i = x / Wrd, w = x - i * Wrd;
-            rows[i * Wsd + w] = w < Wd ? __hip_atomic_load(mask + (size_t)U[i] * (size_t)rstride + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        }
-        __syncthreads();
-        // Most touched vertices are adjacent to fewer than four members.  A wave therefore takes 64 touched
-        // vertices at a time, one per lane: every lane reads and clears the mask of its vertex (the reads of
-        // 64 masks are in flight together) and counts its bits; the vertices with at least four bits are then
-        // taken one after the other by the whole wave.
-        for (int z0 = wave * GPM_WAVE; z0 < nt; z0 += 4 * GPM_WAVE) {
-            const int z = z0 + lane;
-            uint32_t mw[OCTA_MAX_D / 32];
-            int k = 0;
-            if (z < nt) {
-                const int32_t t = __hip_atomic_load(touched + z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int SW = Wd + 1;  // words of a listed set: its mask and its size
+        {
+            const int z = seg * h.seg + tid;
+            if (tid < h.seg && z < nt) {
+                const int32_t t = touched[z];
                 uint32_t *mt = mask + (size_t)t * (size_t)rstride;
                 // only the words that hold bits are read (one, for most vertices)
                 const uint32_t filled = half_word ? 1u : one_word ? 3u : __hip_atomic_load(mt + Wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t mw[OCTA_MAX_D / 32];
+                int k = 0;
 #pragma unroll
                 for (int w = 0; w < OCTA_MAX_D / 32; ++w)
                     mw[w] = (filled >> w) & 1u ? __hip_atomic_load(mt + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
                 for (int w = 0; w < OCTA_MAX_D / 32; ++w) {
                     k += __popc(mw[w]);
-                    if (mw[w]) atomicExch(mt + w, 0u);  // cleared for the next root
+                    if (mw[w]) atomicExch(mt + w, 0u);  // cleared for the next round
                 }
                 if (!one_word) atomicExch(mt + Wd, 0u);
-            } else {
+                if (k >= 4) {
+                    uint32_t *slot = sets + atomicAdd(&s_nsets, 1) * SW;
 #pragma unroll
-                for (int w = 0; w < OCTA_MAX_D / 32; ++w) mw[w] = 0;
-            }
-            unsigned long long big = __ballot(k >= 4);
-            while (big) {
-                const int src = __builtin_ctzll(big);
-                big &= big - 1;
-                // the set's mask, the same in every lane (words from Wd on are zeros)
-                uint32_t um[OCTA_MAX_D / 32];
-#pragma unroll
-                for (int w = 0; w < OCTA_MAX_D / 32; ++w) um[w] = __builtin_amdgcn_readlane(mw[w], src);
-                const int kk = __builtin_amdgcn_readlane(k, src);
-                wave_lds_sync();  // the last set's pairs are done with members[]
-                {  // positions of the mask's bits, in ascending order: lane l lists the bits of word l
-                    int at = 0;
-                    uint32_t bits = 0;
-#pragma unroll
-                    for (int w = 0; w < OCTA_MAX_D / 32; ++w) {
-                        if (lane > w) at += __popc(um[w]);
-                        if (lane == w) bits = um[w];
-                    }
-                    while (bits) {
-                        members[at++] = (uint16_t)(32 * lane + __builtin_ctz(bits));
-                        bits &= bits - 1;
-                    }
+                    for (int w = 0; w < OCTA_MAX_D / 32; ++w)
+                        if (w < Wd) slot[w] = mw[w];
+                    slot[Wd] = (uint32_t)k;
                 }
-                wave_lds_sync();
-                // The kk (kk - 1) / 2 pairs are dealt out to the lanes as one sequence (row p holds the pairs
-                // (p, p + 1) .. (p, kk - 1)): most sets are small, and a lane per pair of one row at a time
-                // would leave most lanes idle.  A lane keeps its place as (p, r) = r-th pair of row p.
-                int pp = 0, r = lane;
+            }
+        }
+        __syncthreads();
+        // The listed sets are dealt out to the waves in turn (the first touched vertices of a heavy root are
+        // its hubs, with the largest sets: neighbours in the list go to different waves).
+        const int nsets = s_nsets;
+        for (int si = wave; si < nsets; si += 4) {
+            const uint32_t *slot = sets + si * SW;
+            // the set's mask, the same in every lane (words from Wd on are zeros)
+            uint32_t um[OCTA_MAX_D / 32];
+#pragma unroll
+            for (int w = 0; w < OCTA_MAX_D / 32; ++w) um[w] = w < Wd ? __builtin_amdgcn_readfirstlane(slot[w]) : 0u;
+            const int kk = (int)__builtin_amdgcn_readfirstlane(slot[Wd]);
+            wave_lds_sync();  // the last set's pairs are done with members[]
+            {  // positions of the mask's bits, in ascending order: lane l lists the bits of word l
+                int at = 0;
+                uint32_t bits = 0;
+#pragma unroll
+                for (int w = 0; w < OCTA_MAX_D / 32; ++w) {
+                    if (lane > w) at += __popc(um[w]);
+                    if (lane == w) bits = um[w];
+                }
+                while (bits) {
+                    members[at++] = (uint16_t)(32 * lane + __builtin_ctz(bits));
+                    bits &= bits - 1;
+                }
+            }
+            wave_lds_sync();
+            // The kk (kk - 1) / 2 pairs are dealt out to the lanes as one sequence (row p holds the pairs
+            // (p, p + 1) .. (p, kk - 1)): most sets are small, and a lane per pair of one row at a time
+            // would leave most lanes idle.  A lane keeps its place as (p, r) = r-th pair of row p.
+            int pp = 0, r = lane;
+            while (pp < kk - 1 && r >= kk - 1 - pp) {
+                r -= kk - 1 - pp;
+                ++pp;
+            }
+            while (pp < kk - 1) {
+                const uint32_t *rp = rows + (int)members[pp] * Wsd, *rq = rows + (int)members[pp + 1 + r] * Wsd;
+                uint32_t c = 0;
+#pragma unroll
+                for (int v = 0; v < OCTA_MAX_D / 128; ++v)
+                    if (v < Wqd)
+                        c = and_popc_add4(and4(load4(rp + 4 * v), u32x4{um[4 * v], um[4 * v + 1], um[4 * v + 2], um[4 * v + 3]}),
+                                          load4(rq + 4 * v), c);
+                twice += (uint64_t)c * (c - (c ? 1u : 0u)) / 2;
+                r += GPM_WAVE;
                 while (pp < kk - 1 && r >= kk - 1 - pp) {
                     r -= kk - 1 - pp;
                     ++pp;
-                }
-                while (pp < kk - 1) {
-                    const uint32_t *rp = rows + (int)members[pp] * Wsd, *rq = rows + (int)members[pp + 1 + r] * Wsd;
-                    uint32_t c = 0;
-#pragma unroll
-                    for (int v = 0; v < OCTA_MAX_D / 128; ++v)
-                        if (v < Wqd)
-                            c = and_popc_add4(and4(load4(rp + 4 * v), u32x4{um[4 * v], um[4 * v + 1], um[4 * v + 2], um[4 * v + 3]}),
-                                              load4(rq + 4 * v), c);
-                    twice += (uint64_t)c * (c - (c ? 1u : 0u)) / 2;
-                    r += GPM_WAVE;
-                    while (pp < kk - 1 && r >= kk - 1 - pp) {
-                        r -= kk - 1 - pp;
-                        ++pp;
-                    }
                 }
             }
         }
     }
     twice = wave_sum_u64(twice);
     if (lane == 0 && twice) atomicAdd(n_copies, (unsigned long long)(twice / 2));
-    if (lane == 0 && bytes) atomicAdd(alg_bytes, (unsigned long long)bytes);
+}
+
+// Work estimate of the octahedron kernel for every root of [lo, hi) (root index i is vertex n-1-i): the
+// entries its members' lists hold above the root -- one mask bit each -- weighted by the width of the universe,
+// which bounds the size of the sets whose pairs are tested.  keys[i - lo] = estimate, verts[i - lo] = vertex.
+__global__ void k_octa_cost(GraphView g, int64_t lo, int64_t hi, uint64_t *keys, int32_t *verts) {
+    const int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    const int32_t u = (int32_t)(g.n - 1 - i);
+    const int64_t ub = g.mid[0][u], ue = g.off[0][u + 1];
+    uint64_t bits = 0;
+    if (ue - ub >= 4)
+        for (int64_t p = ub; p < ue; ++p) {
+            const int32_t x = g.adj[0][p];
+            const int64_t e = g.off[0][x + 1];
+            bits += (uint64_t)(e - lower_bound_g(g.adj[0], g.off[0][x], e, u + 1));
+        }
+    keys[i - lo] = bits * (uint64_t)(8 + (ue - ub)) + 1;
+    verts[i - lo] = u;
 }
 
 // Longest N+ of the graph (the universes of the clique and octahedron kernels).
