@@ -209,6 +209,9 @@ struct DevState {
     uint64_t octa_order_ver = 0;
     std::vector<EventPair> events;
     size_t events_used = 0;
+    // 4-cycle path: completion of the last CLQ_INFLIGHT chunks, one event per slot stream and chunk, so that a
+    // worker is never more than that many chunks ahead of its GPU
+    std::vector<hipEvent_t> ring;
     // results of the last search
     uint64_t canonical = 0, alg_bytes = 0, tail_bytes = 0, chunks = 0;
     uint64_t rows_in[GPM_MAXP] = {};
@@ -290,8 +293,8 @@ struct gpm_ctx {
     // gather rounds of an output-mode search on several GPUs (see gather_round)
     bool gather_on_device = true;     // GPM_GATHER=host: every worker hands its own rows to the host queue instead
     struct {
-        int arrived = 0, finished = 0;
-        uint64_t generation = 0;
+        int arrived = 0, finished = 0, waiting = 0;
+        uint64_t generation = 0, wait_generation = 0;
         std::atomic<bool> requested{false};
         uint64_t rows[2][8] = {};     // per round parity: rows every worker brings
         bool last[2] = {false, false};  // per round parity: every worker had finished when the round formed
@@ -530,6 +533,7 @@ extern "C" void gpm_hip_destroy(gpm_ctx *ctx) {
             (void)hipEventDestroy(ev.a);
             (void)hipEventDestroy(ev.b);
         }
+        for (auto &ev : d.ring) (void)hipEventDestroy(ev);
         for (auto &sl : d.slots) {
             if (sl.done) (void)hipEventDestroy(sl.done);
             if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -1622,6 +1626,24 @@ static int gather_meet(gpm_ctx *ctx, DevState &d, uint64_t rows[8], bool *last) 
     return GPM_OK;
 }
 
+// Plain barrier of the workers inside a round (its own generation counter: the round's bookkeeping --
+// rounds, rows, requested -- is not touched).
+static int gather_wait(gpm_ctx *ctx) {
+    auto &gs = ctx->gs;
+    const int n = (int)ctx->devs.size();
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    const uint64_t gen = gs.wait_generation;
+    if (++gs.waiting == n) {
+        gs.waiting = 0;
+        gs.wait_generation++;
+        ctx->cv.notify_all();
+        return GPM_OK;
+    }
+    ctx->cv.wait(lk, [&] { return gs.wait_generation != gen || ctx->stop; });
+    if (gs.wait_generation == gen) return fail(GPM_ESINK, "the search was stopped");
+    return GPM_OK;
+}
+
 static int deliver(const SearchArgs &a, DevState &d, const int32_t *rows, uint64_t nrows);
 static int deliver_text(const SearchArgs &a, DevState &d, const int32_t *rows_dev, uint64_t nrows);
 
@@ -1675,14 +1697,8 @@ static int gather_round(const SearchArgs &a, DevState &d, bool *last) {
         }
     }
     d.ag_rows = 0;
-    if (ctx->comms.empty()) {  // peer copies read the others' send buffers: nobody refills before GPU 0 is done
-        uint64_t dummy[8];
-        bool dummy_last;
-        uint64_t keep = d.ag_rows;
-        rc = gather_meet(ctx, d, dummy, &dummy_last);
-        d.ag_rows = keep;
-        if (rc) return rc;
-    }
+    // peer copies read the others' send buffers: nobody refills before GPU 0 is done
+    if (ctx->comms.empty() && (rc = gather_wait(ctx))) return rc;
     if (d.index == 0 && all) {
         ctx->gs.gathered_rows += all;
         for (int i = 0; i < n && !ctx->stop; ++i) {
@@ -2329,18 +2345,25 @@ static int prepare_chunks(gpm_ctx *ctx) {
     ctx->cyc_single_roots.clear();
     ctx->cyc_single_v1.clear();
     ctx->cyc_single_ver++;
-    for (size_t h = 0; h < ctx->cyc_heavy_roots.size(); ++h)
-        if (cyc_is_ranged(ctx->cyc_rule, ctx->cyc_heavy_paths[h], (int32_t)(ctx->info.n - 1 - ctx->cyc_heavy_roots[h])) &&
-            ctx->cyc_heavy_arcs[h] <= (int64_t)CYC_HEAVY_WAVES * GPM_WAVE * ctx->cyc_range_tiles) {
+    {
+        std::vector<size_t> single;  // positions in the heavy lists
+        for (size_t h = 0; h < ctx->cyc_heavy_roots.size(); ++h)
+            if (cyc_is_ranged(ctx->cyc_rule, ctx->cyc_heavy_paths[h], (int32_t)(ctx->info.n - 1 - ctx->cyc_heavy_roots[h])) &&
+                ctx->cyc_heavy_arcs[h] <= (int64_t)CYC_HEAVY_WAVES * GPM_WAVE * ctx->cyc_range_tiles)
+                single.push_back(h);
+        // heaviest first: a launch takes every K-th root of this list and the GPU starts its workgroups in order
+        std::stable_sort(single.begin(), single.end(),
+                         [&](size_t a, size_t b) { return ctx->cyc_heavy_paths[a] > ctx->cyc_heavy_paths[b]; });
+        for (size_t h : single) {
             ctx->cyc_single_roots.push_back(ctx->cyc_heavy_roots[h]);
             ctx->cyc_single_v1.push_back((int32_t)(ctx->info.n - 1 - ctx->cyc_heavy_roots[h]));
         }
+    }
     int64_t want = ctx->chunk_hint > 0 ? ctx->chunk_hint : 32 * (int64_t)ctx->devs.size();
-    // The two-path counts are exact costs and every chunk is one persistent launch: few, large chunks.  Several
-    // processes on one cursor need chunks to steal from each other, so there the count is only halved.
+    // the two-path counts are exact costs and every chunk is one persistent launch: few, large chunks
     // chunks of the octahedron path (its own table, below): launches overlap on streams, a quarter of the hint
     const int64_t want_octa = std::max<int64_t>(1, want / 4);
-    if (cyc || (ctx->octa && ctx->use_octa)) want = std::max<int64_t>(1, want / (ctx->shared_cursor ? 2 : 8));
+    if (cyc || (ctx->octa && ctx->use_octa)) want = std::max<int64_t>(1, want / 8);
     // the level-by-level path synchronises with the host several times per chunk: fewer, larger chunks
     else if (!(ctx->clique_k && ctx->use_clique)) want = std::max<int64_t>(1, want / 8);
     // A chunk costs the host a handful of enqueues (microseconds each) whatever it holds: a graph whose whole
@@ -2511,6 +2534,18 @@ static int device_search(const SearchArgs &a, DevState &d) {
         HIP_TRY(hipMemsetAsync(d.cyc_queue, 0, 1024 * sizeof(unsigned long long), s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    // 4-cycles: the heavy roots whose arcs fit one task are worked off apart from the chunks, in `pieces`
+    // launches that come first in the cursor's numbering; piece p takes every pieces-th root of the list
+    // (heaviest first), so each launch holds thousands of workgroups and begins with its longest roots
+    const uint64_t pieces = cyc && ctx->cyc_rule.S && !ctx->cyc_single_v1.empty()
+                                ? std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)env_i64("GPM_CYC_PIECES", (int64_t)ctx->chunks.size() / 4), ctx->cyc_single_v1.size()))
+                                : 0;
+    const uint64_t cyc_ahead = (uint64_t)std::min<int64_t>(CLQ_INFLIGHT, std::max<int64_t>(1, env_i64("GPM_CYC_INFLIGHT", CLQ_INFLIGHT)));
+    uint64_t cyc_items = 0;
+    if (cyc && d.ring.empty()) {
+        d.ring.resize((size_t)CLQ_INFLIGHT * CLQ_INFLIGHT);
+        for (auto &ev : d.ring) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
     uint64_t seq = 0, cyc_heavy_seq = 0, octa_rounds = 0;
     // chunks in flight on the clique path; 1 runs every launch with the GPU to itself (kernel times
     // then add up to the wall time, which is how a kernel's own rate is measured)
@@ -2529,9 +2564,30 @@ static int device_search(const SearchArgs &a, DevState &d) {
             if (fixed_chunk.lo >= ctx->root_hi) break;
         } else {
             c = claim_chunk(ctx);
-            if (c >= table.size()) break;
+            if (c >= table.size() + pieces) break;
         }
-        const Chunk &ch = a.fixed_memory ? fixed_chunk : table[(size_t)c];
+        if (cyc) {  // at most CLQ_INFLIGHT chunks ahead of the GPU: what is not claimed yet is left for other ranks
+            hipEvent_t *ring = d.ring.data() + (cyc_items % cyc_ahead) * CLQ_INFLIGHT;
+            if (cyc_items >= cyc_ahead)
+                for (int i = 0; i < CLQ_INFLIGHT; ++i) HIP_TRY(hipEventSynchronize(ring[i]));
+        }
+        if (cyc && c < pieces) {
+            const int S = ctx->cyc_rule.S;
+            const size_t total = ctx->cyc_single_v1.size();
+            const size_t count = (total - (size_t)c + (size_t)pieces - 1) / (size_t)pieces;  // roots c, c + pieces, ...
+            hipStream_t hs = d.slots[(int)(cyc_heavy_seq++ % CYC_HEAVY_GROUPS) + 1].stream;
+            d.chunks++;
+            if ((rc = timed_begin(d, GPM_KIND_CYCLE4, (int64_t)count, hs))) return rc;
+            k_cycle4_ranges<<<(unsigned)count, CYC_HEAVY_WAVES * GPM_WAVE, CYC_RANGE_LDS_BYTES(S), hs>>>(
+                d.gv, d.cyc_wp, CycBatch{}, d.cyc_single + c, (int)pieces, S, ctx->cyc_range_tiles, nullptr, 0,
+                d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_CYC_BYTES);
+            HIP_TRY(hipGetLastError());
+            if ((rc = timed_end(d, hs))) return rc;
+            hipEvent_t *ring = d.ring.data() + (cyc_items++ % cyc_ahead) * CLQ_INFLIGHT;
+            for (int i = 0; i < CLQ_INFLIGHT; ++i) HIP_TRY(hipEventRecord(ring[i], d.slots[i].stream));
+            continue;
+        }
+        const Chunk &ch = a.fixed_memory ? fixed_chunk : table[(size_t)(c - pieces)];
         const int64_t lo = ch.lo, hi = ch.hi;
         d.chunks++;
         if (octa) {
@@ -2617,20 +2673,6 @@ static int device_search(const SearchArgs &a, DevState &d) {
             const int64_t hblock = ctx->cyc_heavy_block, span = ctx->cyc_span;
             const int S = ctx->cyc_rule.S;
             const size_t h_lo = (size_t)(std::lower_bound(hv.begin(), hv.end(), lo) - hv.begin());
-            if (S) {  // ranged roots of one task each: one launch for all of them
-                const auto &sr = ctx->cyc_single_roots;
-                const size_t i0 = (size_t)(std::lower_bound(sr.begin(), sr.end(), lo) - sr.begin());
-                const size_t i1 = (size_t)(std::lower_bound(sr.begin(), sr.end(), hi) - sr.begin());
-                if (i1 > i0) {
-                    hipStream_t hs = d.slots[(int)(cyc_heavy_seq++ % CYC_HEAVY_GROUPS) + 1].stream;
-                    if ((rc = timed_begin(d, GPM_KIND_CYCLE4, (int64_t)(i1 - i0), hs))) return rc;
-                    k_cycle4_ranges<<<(unsigned)(i1 - i0), CYC_HEAVY_WAVES * GPM_WAVE, CYC_RANGE_LDS_BYTES(S), hs>>>(
-                        d.gv, d.cyc_wp, CycBatch{}, d.cyc_single + i0, S, ctx->cyc_range_tiles, nullptr, 0,
-                        d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_CYC_BYTES);
-                    HIP_TRY(hipGetLastError());
-                    if ((rc = timed_end(d, hs))) return rc;
-                }
-            }
             for (int ranged = S ? 1 : 0; ranged >= 0; --ranged) {
                 size_t h = h_lo;
                 while (h < hv.size() && hv[h] < hi) {
@@ -2643,7 +2685,7 @@ static int device_search(const SearchArgs &a, DevState &d) {
                         if (cyc_is_ranged(ctx->cyc_rule, paths, v1) != (bool)ranged) continue;
                         const int64_t block_arcs = (int64_t)CYC_HEAVY_WAVES * GPM_WAVE * ctx->cyc_range_tiles;
                         const int64_t tasks = ranged ? (ctx->cyc_heavy_arcs[h] + block_arcs - 1) / block_arcs : (paths + span - 1) / span;
-                        if (ranged && tasks == 1) continue;  // launched above
+                        if (ranged && tasks == 1) continue;  // in one of the launches of single-task roots
                         if (b.n && (int64_t)b.wg0[b.n] + tasks > (int64_t)1 << 20) break;  // next launch
                         b.v1[b.n] = v1;
                         shared_arrays |= tasks > 1;
@@ -2658,7 +2700,7 @@ static int device_search(const SearchArgs &a, DevState &d) {
                     if ((rc = timed_begin(d, GPM_KIND_CYCLE4, b.n, hs))) return rc;
                     if (ranged)
                         k_cycle4_ranges<<<(unsigned)b.wg0[b.n], CYC_HEAVY_WAVES * GPM_WAVE, CYC_RANGE_LDS_BYTES(S), hs>>>(
-                            d.gv, d.cyc_wp, b, nullptr, S, ctx->cyc_range_tiles, dense, d.cyc_stride, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_CYC_BYTES);
+                            d.gv, d.cyc_wp, b, nullptr, 1, S, ctx->cyc_range_tiles, dense, d.cyc_stride, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_CYC_BYTES);
                     else
                         k_cycle4_heavy<<<(unsigned)b.wg0[b.n], CYC_HEAVY_WAVES * GPM_WAVE, CYC_HEAVY_LDS_BYTES, hs>>>(
                             d.gv, d.cyc_wp, b, dense, d.cyc_stride, span, hblock, d.ctr + CTR_TAIL_MATCHES, d.ctr + CTR_CYC_BYTES);
@@ -2674,6 +2716,8 @@ static int device_search(const SearchArgs &a, DevState &d) {
                     }
                 }
             }
+            hipEvent_t *ring = d.ring.data() + (cyc_items++ % cyc_ahead) * CLQ_INFLIGHT;
+            for (int i = 0; i < CLQ_INFLIGHT; ++i) HIP_TRY(hipEventRecord(ring[i], d.slots[i].stream));
             continue;
         }
         if (clique) {
@@ -2774,7 +2818,7 @@ static int search_impl(gpm_ctx *ctx, int count_only, gpm_row_sink sink, gpm_text
     const bool threaded = ctx->devs.size() > 1 || (!ctx->comms.empty() && !count_only);
     SearchArgs a{ctx, count_only != 0, !threaded, sink, user, text_sink};
     a.gather = !count_only && threaded && ctx->gather_on_device;
-    ctx->gs.arrived = ctx->gs.finished = 0;
+    ctx->gs.arrived = ctx->gs.finished = ctx->gs.waiting = 0;
     ctx->gs.requested = false;
     ctx->gs.rounds = ctx->gs.gathered_rows = 0;
     int rc = GPM_OK;

@@ -2505,15 +2505,16 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_heavy(Grap
 // all inside one 4 S-byte piece of the array.  A task ends with the range in
 // which its last list runs out.
 // Workgroups wg0[r] .. wg0[r + 1] are the arc blocks of root r of the batch;
-// with an empty batch workgroup i is the only block of root singles[i] (any
-// number of roots per launch, the list lives in global memory).
+// with an empty batch workgroup i is the only block of root singles[i * single_step]
+// (any number of roots per launch, the list lives in global memory, heaviest root
+// first: a launch takes every single_step-th root of it).
 // Dynamic LDS (words): cnt[S] | s_beg[16][64] (int64) | s_pre[16][64].
 #define CYC_RANGE_MAX_IDS 32768
 #define CYC_RANGE_TILES 4
 #define CYC_RANGE_LDS_BYTES(S) ((S) * 4 + CYC_HEAVY_WAVES * GPM_WAVE * 12)
 
 __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(GraphView g, const int64_t *wp, CycBatch b,
-                                                                            const int32_t *singles, int S, int tiles,
+                                                                            const int32_t *singles, int single_step, int S, int tiles,
                                                                             uint32_t *dense, int64_t stride,
                                                                             unsigned long long *n_cycles,
                                                                             unsigned long long *alg_bytes) {
@@ -2529,7 +2530,7 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
         if (b.wg0[m] <= (int)blockIdx.x) r = m;
         else hi = m;
     }
-    const int32_t v1 = b.n ? b.v1[r] : singles[blockIdx.x];
+    const int32_t v1 = b.n ? b.v1[r] : singles[(size_t)blockIdx.x * (size_t)single_step];
     const int64_t *off = g.off[0];
     const int32_t *adj = g.adj[0];
     const int64_t lb = off[v1], le = g.mid[0][v1];
