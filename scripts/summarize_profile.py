@@ -18,10 +18,10 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
-SEARCH = ("k_clique", "k_clq_", "k_cycle4", "k_octa", "k_tail", "k_leaf_pair", "k_extend", "k_ranges", "k_filter_roots", "k_batch_end",
+SEARCH = ("k_clique", "k_clq_", "k_cycle4", "k_octa", "k_tail", "k_leaf_pair", "k_leaf_suffix", "k_extend", "k_ranges", "k_filter_roots", "k_batch_end",
           "k_sum_slots")
 # kernel family (the names gpm_hip_kernel_name returns) -> prefixes of the kernels in it
-FAMILIES = {"k_tail": ("k_tail", "k_leaf_pair"), "k_extend": ("k_extend",), "k_clique": ("k_clique<", "k_clique_tiny<"),
+FAMILIES = {"k_tail": ("k_tail", "k_leaf_pair", "k_leaf_suffix"), "k_extend": ("k_extend",), "k_clique": ("k_clique<", "k_clique_tiny<"),
             "k_clq_build": ("k_clq_build",), "k_clq_count4": ("k_clq_count4",), "k_cycle4": ("k_cycle4_light", "k_cycle4_heavy", "k_cycle4_ranges"), "k_octa": ("k_octa",)}
 
 
@@ -152,7 +152,9 @@ traffic["hbm_bytes_per_search"] = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"]
 # for the others: a tag that names a configuration (e.g. r2_config2) writes the latter
 import re
 cfg_tag = re.search(r"config(\d+)", tag)
-traffic_name = f"config{cfg_tag.group(1)}_hbm_traffic.json" if cfg_tag else "hbm_traffic.json"
+# a tag of the form <round>_<name> (a pattern other than the configurations') keeps its traffic under that name
+traffic_name = (f"config{cfg_tag.group(1)}_hbm_traffic.json" if cfg_tag
+                else "hbm_traffic.json" if re.fullmatch(r"r\d+[a-z]?", tag) else f"{tag}_hbm_traffic.json")
 with open(os.path.join(dst, traffic_name), "w") as f:
     json.dump(traffic, f, indent=1)
     f.write("\n")
