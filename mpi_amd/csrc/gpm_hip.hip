@@ -293,6 +293,7 @@ struct gpm_ctx {
     // gather rounds of an output-mode search on several GPUs (see gather_round)
     bool gather_on_device = true;     // GPM_GATHER=host: every worker hands its own rows to the host queue instead
     struct {
+        bool round_failed = false;  // a worker could not prepare its part of the current round
         int arrived = 0, finished = 0, waiting = 0;
         uint64_t generation = 0, wait_generation = 0;
         std::atomic<bool> requested{false};
@@ -1664,12 +1665,31 @@ static int gather_round(const SearchArgs &a, DevState &d, bool *last) {
     }
     DevState &d0 = ctx->devs[0];
     if (all) {
+        // What a worker has to do before the exchange (here: its row count on the device) can fail, and a
+        // collective that one rank never joins blocks the others for good.  So every worker reports how its
+        // preparation went, all meet once more, and the exchange is issued only if nobody failed.
+        // GPM_FAULT_GATHER=<worker> makes that worker report a failure in its first round (tests).
+        bool prep_ok = true;
+        if (!ctx->comms.empty()) {
+            d.ctr_host[CTR_CLQ_CLASS0] = d.ag_rows;
+            prep_ok = hipMemcpyAsync(d.ag_counts, d.ctr_host + CTR_CLQ_CLASS0, sizeof(unsigned long long),
+                                     hipMemcpyHostToDevice, s) == hipSuccess;
+        }
+        const int64_t fault_worker = env_i64("GPM_FAULT_GATHER", -1);
+        if (fault_worker == d.index) prep_ok = false;
+        if (!prep_ok) {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            ctx->gs.round_failed = true;
+        }
+        if ((rc = gather_wait(ctx))) return rc;
+        if (ctx->gs.round_failed) {
+            ctx->stop = true;
+            ctx->cv.notify_all();
+            return fail(GPM_ERUNTIME, "worker %d: a worker could not prepare its part of a gather round", d.index);
+        }
         if (!ctx->comms.empty()) {
             const Rccl &R = rccl();
             // row counts first (every GPU learns how much of each padded list is real), then the lists
-            d.ctr_host[CTR_CLQ_CLASS0] = d.ag_rows;
-            HIP_TRY(hipMemcpyAsync(d.ag_counts, d.ctr_host + CTR_CLQ_CLASS0, sizeof(unsigned long long),
-                                   hipMemcpyHostToDevice, s));
             int nrc = R.AllGather(d.ag_counts, d.ag_counts + 1, 1, RCCL_UINT64, ctx->comms[(size_t)d.index], s);
             if (nrc == 0)
                 nrc = R.AllGather(d.ag_send, d.ag_recv, (size_t)longest * (size_t)P, RCCL_INT32,
@@ -2819,6 +2839,7 @@ static int search_impl(gpm_ctx *ctx, int count_only, gpm_row_sink sink, gpm_text
     SearchArgs a{ctx, count_only != 0, !threaded, sink, user, text_sink};
     a.gather = !count_only && threaded && ctx->gather_on_device;
     ctx->gs.arrived = ctx->gs.finished = ctx->gs.waiting = 0;
+    ctx->gs.round_failed = false;
     ctx->gs.requested = false;
     ctx->gs.rounds = ctx->gs.gathered_rows = 0;
     int rc = GPM_OK;

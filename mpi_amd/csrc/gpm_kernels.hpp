@@ -2556,18 +2556,19 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
     }
     if (threadIdx.x == 0) s_top[0] = s_top[1] = -1;
     uint64_t acc = 0;
+    // The last entry of every list that has entries left, all tiles requested together; the highest of them
+    // over the workgroup is where a pass's range ends, so no pass is spent on ids nobody has left, and a list
+    // has entries in the range exactly when its last entry is at or above id_lo.  The entries for the next
+    // pass are requested as soon as a list's piece for this pass is known, so that the read is under way
+    // while the piece is counted.
+    int32_t last[CYC_RANGE_TILES];
+#pragma unroll
+    for (int k = 0; k < CYC_RANGE_TILES; ++k) last[k] = left[k] ? adj[lo[k] + left[k] - 1] : -1;
     for (int pass = 0;; ++pass) {
         __syncthreads();  // the last pass is over (walk and flush), s_top[pass & 1] is -1
-        // The last entry of every list that has entries left, all tiles requested together; the highest
-        // of them over the workgroup is where this pass's range ends, so no pass is spent on ids nobody has
-        // left, and a list has entries in the range exactly when its last entry is at or above id_lo.
-        int32_t last[CYC_RANGE_TILES];
         int32_t top = -1;
 #pragma unroll
-        for (int k = 0; k < CYC_RANGE_TILES; ++k) {
-            last[k] = left[k] ? adj[lo[k] + left[k] - 1] : -1;
-            top = max(top, last[k]);
-        }
+        for (int k = 0; k < CYC_RANGE_TILES; ++k) top = max(top, last[k]);
         for (int x = threadIdx.x; x < S / 4; x += blockDim.x) reinterpret_cast<uint4 *>(cnt)[x] = make_uint4(0u, 0u, 0u, 0u);
         for (int o = 32; o > 0; o >>= 1) top = max(top, __shfl_xor(top, o, GPM_WAVE));
         if (lane == 0 && top >= 0) atomicMax(&s_top[pass & 1], top);
@@ -2599,6 +2600,7 @@ __global__ __launch_bounds__(CYC_HEAVY_WAVES *GPM_WAVE) void k_cycle4_ranges(Gra
             const uint32_t len = left[k] - keep;
             const int64_t beg = lo[k] + keep;
             left[k] = keep;
+            last[k] = keep ? adj[lo[k] + keep - 1] : -1;  // for the next pass
             const uint32_t incl = wave_incl_scan_u32(len);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, GPM_WAVE - 1);
             if (total == 0) continue;

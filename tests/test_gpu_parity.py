@@ -825,6 +825,30 @@ def test_several_workers_in_one_context(workers, gather, monkeypatch):
         m.close()
 
 
+def test_a_worker_that_fails_inside_a_gather_round_ends_the_search(monkeypatch):
+    """Fault injection: worker 1 of two reports that it could not prepare its part of the first gather round.
+    Every worker learns of it at the round's second meeting and none issues the exchange, so the search ends
+    with an error instead of leaving the others in a collective nobody completes; the next search of a fresh
+    context is unaffected."""
+    monkeypatch.setenv("GPM_NO_RCCL", "1")
+    spec = next(g for g in GOLDEN if g["name"] == "rmat10_clique4")
+    n, s, d = util.build_graph(spec)
+    monkeypatch.setenv("GPM_FAULT_GATHER", "1")
+    m = binding.Matcher(2, devices=[0, 0])
+    upload(m, n, s, d)
+    m.set_pattern(gen.PATTERNS["clique4"])
+    m.set_chunks(40)
+    with pytest.raises(binding.GpmError, match="gather round|stopped"):
+        m.findMatches(count_only=False)
+    m.close()
+    monkeypatch.delenv("GPM_FAULT_GATHER")
+    m = binding.Matcher(2, devices=[0, 0])
+    upload(m, n, s, d)
+    m.set_pattern(gen.PATTERNS["clique4"])
+    assert len(m.findMatches(count_only=False)) == spec["count"]
+    m.close()
+
+
 def test_chunk_count_does_not_change_the_result():
     n, s, d = util.build_graph({"graph": "rmat", "scale": 12, "ef": 8, "seed": 1})
     m = binding.Matcher(1)

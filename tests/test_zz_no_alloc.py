@@ -80,3 +80,22 @@ def test_sizes_beyond_the_maximum_are_rejected(monkeypatch):
     with pytest.raises(binding.GpmError):
         m2.countNoAlloc()
     m2.close()
+
+
+def test_a_context_that_shares_its_cursor_is_rejected():
+    """The call walks every root itself; on a context whose chunk cursor other processes share the
+    per-process counts would no longer add up to the whole, so it refuses (and works again once the
+    cursor is private)."""
+    import ctypes
+    n, s, d = util.build_graph({"graph": "rmat", "scale": 8, "ef": 8, "seed": 1})
+    m = binding.Matcher(1)
+    upload(m, n, s, d)
+    m.set_pattern(gen.PATTERNS["triangle"])
+    want = m.findMatches(count_only=True)
+    word = ctypes.c_uint64(0)
+    m.set_cursor(ctypes.addressof(word))
+    with pytest.raises(binding.GpmError, match="shares a chunk cursor"):
+        m.countNoAlloc()
+    m.set_cursor(None)
+    assert m.countNoAlloc() == want
+    m.close()
