@@ -178,6 +178,11 @@ struct DevState {
     int clq_scratch_blocks = 0;
     int clq_probe_bias = 0;    // GPM_CLIQUE_PROBE_BIAS, read once per context
     bool count4_wide = true;   // GPM_COUNT4_WAVES >= 16
+    // GPM_COUNT4_VT_<class 2..5>: columns per tile of the count (256, 512, 1024).  Tiles of 512 leave out a quarter
+    // of the words a universe of 1024 would AND and let two workgroups share a compute unit; tiles of 256 list
+    // every row's bits so often that the listing costs more than the ANDs saved.
+    int count4_vt[4] = {512, 512, 512, 1024};
+    int count4_wide_min = 512;  // GPM_COUNT4_WIDE_MIN: tiles of at least this many columns are counted by 16 waves
     int clq_lists_max_class = 5;  // GPM_CLQ_LISTS_MAX_CLASS: size classes up to this one build their rows from the
                                   // adjacency lists, larger ones from hub-matrix gathers (1 = gathers only)
     int clq_build_rb = 0;         // GPM_CLQ_BUILD_RB: workgroups per root of that kernel (0 = by size class)
@@ -629,6 +634,13 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
     for (auto &d : ctx->devs) {
         d.clq_probe_bias = (int)env_i64("GPM_CLIQUE_PROBE_BIAS", 0);
         d.count4_wide = env_i64("GPM_COUNT4_WAVES", 16) >= 16;
+        for (int c = 2; c <= 5; ++c) {
+            char name[32];
+            snprintf(name, sizeof name, "GPM_COUNT4_VT_%d", c);
+            const int64_t vt = env_i64(name, d.count4_vt[c - 2]);
+            d.count4_vt[c - 2] = vt <= 256 ? 256 : vt <= 512 ? 512 : 1024;
+        }
+        d.count4_wide_min = (int)env_i64("GPM_COUNT4_WIDE_MIN", d.count4_wide_min);
         d.clq_lists_max_class = (int)env_i64("GPM_CLQ_LISTS_MAX_CLASS", 5);
         d.clq_build_rb = (int)env_i64("GPM_CLQ_BUILD_RB", 0);
         d.clq_lists_waves = env_i64("GPM_CLQ_LISTS_WAVES", 16) == 4 ? 4 : 16;
@@ -2030,11 +2042,11 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CL
         const size_t lds_build = ((size_t)(ALL_HUB && !STATS ? 1 : 4) * dcap + 4 * 128) * sizeof(uint32_t);
         // 16 waves hide the LDS latency of the big tiles better than 8; the J lists of 16 waves and a
         // 128 KiB tile fill the 160 KiB of LDS exactly
-        const bool wide = dcap > 512 && d.count4_wide;
+        const int vt = std::min(dcap, d.count4_vt[c - 2]);  // columns per tile of the count
+        const bool wide = vt >= d.count4_wide_min && d.count4_wide;
         const int nw = wide ? 16 : 8, seg = wide ? 2 : 4;
-        const size_t lds_count = ((size_t)nw * 512 + (size_t)std::min(dcap, 1024) * (std::min(dcap, 1024) / 32)) *
-                                 sizeof(uint32_t);
-        const int tcap = dcap > 1024 ? dcap / 1024 : 1, phases = tcap * (tcap + 1) / 2;
+        const size_t lds_count = ((size_t)nw * (vt / 2) + (size_t)vt * (vt / 32)) * sizeof(uint32_t);
+        const int tcap = dcap / vt, phases = tcap * (tcap + 1) / 2;
         for (int64_t b0 = 0; b0 < (int64_t)n[c]; b0 += batch) {
             const int64_t nb = std::min<int64_t>(batch, (int64_t)n[c] - b0);
             if ((rc = timed_begin(d, GPM_KIND_CLQ_BUILD, nb, s, c))) return rc;
@@ -2042,7 +2054,7 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CL
                 // rows from the adjacency lists, tested against a bitmap of the universe in LDS
                 const int RB = d.clq_build_rb > 0 ? d.clq_build_rb : (c == 2 ? 1 : c == 3 ? 2 : c == 4 ? 4 : 8);
                 const int nwl = d.clq_lists_waves;
-                const size_t lds_lists = ((size_t)bm_words + bm_words / 2 + dcap + (size_t)nwl * 128) * sizeof(uint32_t);
+                const size_t lds_lists = ((size_t)bm_words + bm_words / 4 + dcap + (size_t)nwl * 128) * sizeof(uint32_t);
                 if (nwl == 16) {
                     HIP_TRY(hipFuncSetAttribute((const void *)k_clq_build_lists<K, 16>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists));
@@ -2069,12 +2081,12 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CL
                     HIP_TRY(hipFuncSetAttribute((const void *)k_clq_count4<2, 16>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
                     k_clq_count4<2, 16><<<(unsigned)(nb * phases * seg), 1024, lds_count, s>>>(d.gv, list + b0, nb, dcap,
-                                                                                                sl.rows, stride, cnt);
+                                                                                                vt / 32, sl.rows, stride, cnt);
                 } else {
                     HIP_TRY(hipFuncSetAttribute((const void *)k_clq_count4<4, 8>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
                     k_clq_count4<4, 8><<<(unsigned)(nb * phases * seg), 512, lds_count, s>>>(d.gv, list + b0, nb, dcap,
-                                                                                              sl.rows, stride, cnt);
+                                                                                              vt / 32, sl.rows, stride, cnt);
                 }
                 HIP_TRY(hipGetLastError());
                 if ((rc = timed_end(d, s))) return rc;

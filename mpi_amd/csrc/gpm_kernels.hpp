@@ -1772,7 +1772,7 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
 // at least `kappa4` / 4 entries per position above it is gathered from the hub
 // matrix instead (every vertex of the launch's universes is a hub), one bit
 // per position; kappa4 < 0: never.
-// LDS (words): bitmap[bm_words] | prefix[bm_words / 2] (16-bit) | U[dcap] | stage[NW][128].
+// LDS (words): bitmap[bm_words] | prefix[bm_words / 4] (16-bit, one per word pair) | U[dcap] | stage[NW][128].
 #define CLQ_BM_MAX_WORDS 16384  // ids a bitmap can cover: 2^19
 #define CLQ_LIST_LOADS 8        // list reads in flight per lane and row
 
@@ -1795,9 +1795,9 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
     const int d = (int)(off[u + 1] - ub);
     if (rb >= d) return;
     uint32_t *bm = smem;                                                  // bm_words is a multiple of 1024
-    uint16_t *prefix = reinterpret_cast<uint16_t *>(smem + bm_words);     // set bits before each bitmap word
-    int32_t *U = (int32_t *)(smem + bm_words + bm_words / 2);
-    uint32_t *stage = smem + bm_words + bm_words / 2 + dcap + wave * 128;
+    uint16_t *prefix = reinterpret_cast<uint16_t *>(smem + bm_words);     // set bits before each pair of bitmap words
+    int32_t *U = (int32_t *)(smem + bm_words + bm_words / 4);
+    uint32_t *stage = smem + bm_words + bm_words / 4 + dcap + wave * 128;
     for (int k = tid; k < bm_words / 4; k += NT) reinterpret_cast<uint4 *>(bm)[k] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     for (int i = tid; i < d; i += NT) {
@@ -1821,8 +1821,9 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
         uint32_t before = incl - mine;
         for (int w = 0; w < wave; ++w) before += s_wave_sum[w];
         for (int k = 0; k < wpt; ++k) {
-            prefix[tid * wpt + k] = (uint16_t)before;
-            before += __popc(bm[tid * wpt + k]);
+            const int w = tid * wpt + k;
+            if (!(w & 1)) prefix[w >> 1] = (uint16_t)before;
+            before += __popc(bm[w]);
         }
     }
     __syncthreads();
@@ -1882,8 +1883,9 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
                 if (K == 3) {
                     tri += 1;
                 } else {
-                    const uint32_t bit = 1u << (c & 31);
-                    const int j = (int)prefix[c >> 5] + __popc(word & (bit - 1));  // rank among the set bits = position in U
+                    // rank among the set bits = position in U: the count before the word pair, plus the pair's bits below
+                    const uint64_t pair = reinterpret_cast<const uint64_t *>(bm)[c >> 6];
+                    const int j = (int)prefix[c >> 6] + __popcll(pair & ((1ull << (c & 63)) - 1ull));
                     atomicOr(stage + (j >> 5), 1u << (j & 31));
                 }
             };
@@ -2002,12 +2004,18 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
 // use one list.
 template <int SEG, int NW>
 __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
-                                                    const uint32_t *rows_buf, int64_t stride_words,
+                                                    int vt_words, const uint32_t *rows_buf, int64_t stride_words,
                                                     unsigned long long *n_matches) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // the wave number read as a scalar: row numbers, row addresses and loop tests then stay out of the vector unit
     const int tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid / GPM_WAVE);
-    const int tcap = dcap > 1024 ? dcap >> 10 : 1;  // column tiles a root of this class can have
+    // The count runs over tiles of VT = 32 * vt_words columns (256, 512 or 1024) cut out of the stored tiles
+    // of 1024: row j's bits lie above j, so against a row j of tile a only the tiles b >= a hold
+    // anything, and the narrower the tiles, the fewer empty words of the rows j near a universe's end
+    // (where the bits of a row crowd) are read and ANDed.  Narrow tiles also take less LDS: more
+    // workgroups share a compute unit, and one's copy into LDS runs under the others' counting.
+    const int VT = 32 * vt_words;
+    const int tcap = dcap > VT ? dcap / VT : 1;      // tiles a root of this class can have
     const int phases = tcap * (tcap + 1) / 2;        // tile pairs (a, b), a <= b
     const int64_t ri = blockIdx.x / (phases * SEG);
     const int ph = (int)(blockIdx.x / SEG) % phases;
@@ -2021,44 +2029,57 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
         ta++;
     }
     tb += ta;
-    if (tb >= big_tiles(d)) return;
+    if (VT * tb >= d) return;
     const uint32_t *region = rows_buf + ri * stride_words;
 
     // what this task holds in LDS and walks: the rows j of tile a restricted to the columns of tile b;
     // rows i < j_hi are walked, their bits over tile a list the j, their words over tile b are ANDed
-    const int j_lo = 1024 * ta, j_hi = big_rows(d, ta), i_hi = j_hi;
-    const int Wt = big_words(d, tb), Wj = big_words(d, ta);
-    const uint32_t *xsrc = region + big_off(tb);                 // row i's words over the column tile
-    const uint32_t *jsrc = region + big_off(ta);                 // row i's words over the row tile's positions
-    const uint32_t *tile_rows = xsrc + (size_t)j_lo * Wt;        // rows j_lo.. of the column tile
-    uint16_t *J = (uint16_t *)smem + wave * 1024;
-    uint32_t *tile = smem + NW * 512;
+    const int j_lo = VT * ta, j_hi = min(d, VT * (ta + 1)), i_hi = j_hi;
+    // stored tile and word offset inside its rows of the two tiles
+    const int sa = (VT * ta) >> 10, wa = ((VT * ta) & 1023) >> 5, sb = (VT * tb) >> 10, wb = ((VT * tb) & 1023) >> 5;
+    const int Wsa = big_words(d, sa), Wsb = big_words(d, sb);  // words of a stored row
+    const int Wt = min(vt_words, Wsb - wb), Wj = min(vt_words, Wsa - wa);
+    const uint32_t *xsrc = region + big_off(sb) + wb;            // row i's words over the column tile, rows Wsb apart
+    const uint32_t *jsrc = region + big_off(sa) + wa;            // row i's words over the row tile's positions, rows Wsa apart
+    const uint32_t *tile_rows = xsrc + (size_t)j_lo * Wsb;       // rows j_lo.. of the column tile
+    uint16_t *J = (uint16_t *)smem + wave * VT;                  // a list holds at most VT entries
+    uint32_t *tile = smem + NW * (VT / 2);
     const int lg = Wt <= 4 ? 0 : Wt <= 8 ? 1 : Wt <= 16 ? 2 : 3;  // Wt <= 32
     const int L = 1 << lg, sub = lane & (L - 1), blk = lane >> lg;
     const bool lane_ok = 4 * sub < Wt;
     {
         // Rows copied in at a stride of L slots; the slots past a row's Wt / 4 are never read.  The copy runs
-        // over the source (one contiguous piece of nrows * Wq 16-byte words): every read of a full batch is
-        // issued without a condition, so eight of them are in flight per thread.  Only one workgroup fits a
-        // compute unit with the big tiles, and nothing else hides this copy's latency.
-        const int Wq = Wt >> 2, nsrc = (j_hi - j_lo) * Wq;
+        // over the nrows * Wq 16-byte words to fetch: every read of a full batch is issued without a
+        // condition, so eight of them are in flight per thread.  Only one workgroup fits a compute unit
+        // with the big tiles, and nothing else hides this copy's latency.
+        const int Wq = Wt >> 2, Wsq = Wsb >> 2, nsrc = (j_hi - j_lo) * Wq;
         const uint32_t inv = (65536u + (uint32_t)Wq - 1u) / (uint32_t)Wq;  // q / Wq == (q * inv) >> 16 for q < 8192, Wq <= 8
         const uint4 *src = reinterpret_cast<const uint4 *>(tile_rows);
         uint4 *dst = reinterpret_cast<uint4 *>(tile);
         constexpr int NT = NW * GPM_WAVE, FILL = 8;
-        auto slot_of = [&](int q) {
-            const int row = (int)(((uint32_t)q * inv) >> 16);
-            return (row << lg) + (q - row * Wq);
+        int row, col;
+        auto split = [&](int q) {
+            row = (int)(((uint32_t)q * inv) >> 16);
+            col = q - row * Wq;
         };
         int q0 = tid;
         for (; q0 + (FILL - 1) * NT < nsrc; q0 += FILL * NT) {
             uint4 v[FILL];
 #pragma unroll
-            for (int f = 0; f < FILL; ++f) v[f] = src[q0 + f * NT];
+            for (int f = 0; f < FILL; ++f) {
+                split(q0 + f * NT);
+                v[f] = src[row * Wsq + col];
+            }
 #pragma unroll
-            for (int f = 0; f < FILL; ++f) dst[slot_of(q0 + f * NT)] = v[f];
+            for (int f = 0; f < FILL; ++f) {
+                split(q0 + f * NT);
+                dst[(row << lg) + col] = v[f];
+            }
         }
-        for (; q0 < nsrc; q0 += NT) dst[slot_of(q0)] = src[q0];
+        for (; q0 < nsrc; q0 += NT) {
+            split(q0);
+            dst[(row << lg) + col] = src[row * Wsq + col];
+        }
     }
     __syncthreads();
 
@@ -2071,7 +2092,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
     // entries): entry t of one and entry t of the other then never lie on the same LDS bank, which they
     // would if the second list started half way (1024 bytes on).
     // this lane block's first entry and the distance (in entries, signed) between two of its entries
-    const uint16_t *Jfirst = my_res ? J + 1023 - my_first : J + my_first;
+    const uint16_t *Jfirst = my_res ? J + VT - 1 - my_first : J + my_first;
     const int jstep = my_res ? -my_step : my_step;
     // listing: lane l looks at four bits of each of the words (l & 7) + 8 k, k = 0..3: bits 4 (l >> 3) .. + 3.
     // A row is dense where its universe holds the highest-degree vertices (its last positions), and a lane
@@ -2089,8 +2110,8 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
     uint32_t mine = 0;
     u32x4 C = {0u, 0u, 0u, 0u};
     if (i < i_hi) {
-        if (word_of_lane < Wj) mine = jsrc[(size_t)i * Wj + word_of_lane];
-        if (lane_ok) C = load4(xsrc + (size_t)i * Wt + 4 * sub);
+        if (word_of_lane < Wj) mine = jsrc[(size_t)i * Wsa + word_of_lane];
+        if (lane_ok) C = load4(xsrc + (size_t)i * Wsb + 4 * sub);
     }
     while (i < i_hi) {
         // list the set bits of row i over tile a
@@ -2105,7 +2126,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
         // next free entry, even / odd list.  Bit b of `bits` is position pos0 + 256 (b >> 2) + (b & 3) (word
         // (b >> 2) * 8 further on), an entry is that position's slot offset.  One loop per list keeps the
         // parity out of the loop body.
-        uint16_t *at0 = J + ((incl - c) & 0xffffu), *at1 = J + 1023 - ((incl - c) >> 16);
+        uint16_t *at0 = J + ((incl - c) & 0xffffu), *at1 = J + VT - 1 - ((incl - c) >> 16);
         const uint32_t entry0 = pos0 << lg;
         uint32_t be = two ? bits & 0x5555u : bits, bo = two ? bits & 0xaaaau : 0u;
         while (be) {
@@ -2123,8 +2144,8 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
         uint32_t mine_n = 0;
         u32x4 C_n = {0u, 0u, 0u, 0u};
         if (inext < i_hi) {
-            if (word_of_lane < Wj) mine_n = jsrc[(size_t)inext * Wj + word_of_lane];
-            if (lane_ok) C_n = load4(xsrc + (size_t)inext * Wt + 4 * sub);
+            if (word_of_lane < Wj) mine_n = jsrc[(size_t)inext * Wsa + word_of_lane];
+            if (lane_ok) C_n = load4(xsrc + (size_t)inext * Wsb + 4 * sub);
         }
         const int my_len = (int)(my_res ? all >> 16 : all & 0xffffu);
         wave_lds_sync();
