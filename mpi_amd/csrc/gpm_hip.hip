@@ -183,12 +183,16 @@ struct DevState {
     // every row's bits so often that the listing costs more than the ANDs saved.
     int count4_vt[4] = {512, 512, 512, 1024};
     int count4_wide_min = 512;  // GPM_COUNT4_WIDE_MIN: tiles of at least this many columns are counted by 16 waves
+    // Diagnostics that give wrong counts (a warning says so): GPM_CLQ_PROBE=1 the list kernel reads its lists and
+    // tests nothing, =2 the same with half of every list; GPM_COUNT4_PROBE=1 the count kernel lists and ANDs nothing.
+    int clq_probe = 0, count4_probe = 0;
     int clq_lists_max_class = 5;  // GPM_CLQ_LISTS_MAX_CLASS: size classes up to this one build their rows from the
                                   // adjacency lists, larger ones from hub-matrix gathers (1 = gathers only)
     int clq_build_rb = 0;         // GPM_CLQ_BUILD_RB: workgroups per root of that kernel (0 = by size class)
     int clq_lists_waves = 16;     // GPM_CLQ_LISTS_WAVES: waves per workgroup of that kernel (4 or 16)
-    int clq_kappa4 = 6;           // GPM_CLQ_KAPPA4: a row of that kernel whose list has this many quarter entries per
-                                  // position left to test is gathered from the hub matrix instead (-1: never)
+    // GPM_CLQ_KAPPA4 (all classes) / GPM_CLQ_KAPPA4_<class 2..5>: a row of that kernel whose list has this many quarter
+    // entries per position left to test is gathered from the hub matrix instead (-1: never)
+    int clq_kappa4[4] = {6, 6, 3, 3};  // the big universes gather more of their rows: measured per class on the headline graph
     unsigned long long *clq_slots = nullptr;  // [0,CLQ_SLOTS) matches, [CLQ_SLOTS,2*CLQ_SLOTS) bytes
     // 4-cycle path: two-path count of every root, counter arrays (cyc_blocks of them for the workgroups of
     // the light kernel, then CYC_HEAVY_GROUPS groups of cyc_batch for heavy roots), root queues of the light
@@ -641,10 +645,20 @@ extern "C" int gpm_hip_create(int ngpus, const int *devices, gpm_ctx **out) {
             d.count4_vt[c - 2] = vt <= 256 ? 256 : vt <= 512 ? 512 : 1024;
         }
         d.count4_wide_min = (int)env_i64("GPM_COUNT4_WIDE_MIN", d.count4_wide_min);
+        d.clq_probe = (int)env_i64("GPM_CLQ_PROBE", 0);
+        d.count4_probe = (int)env_i64("GPM_COUNT4_PROBE", 0);
+        if (d.clq_probe || d.count4_probe) {
+            static std::atomic<bool> warned{false};
+            if (!warned.exchange(true)) fprintf(stderr, "gpm: GPM_CLQ_PROBE / GPM_COUNT4_PROBE set: clique counts are wrong (diagnostic run)\n");
+        }
         d.clq_lists_max_class = (int)env_i64("GPM_CLQ_LISTS_MAX_CLASS", 5);
         d.clq_build_rb = (int)env_i64("GPM_CLQ_BUILD_RB", 0);
         d.clq_lists_waves = env_i64("GPM_CLQ_LISTS_WAVES", 16) == 4 ? 4 : 16;
-        d.clq_kappa4 = (int)env_i64("GPM_CLQ_KAPPA4", 6);
+        for (int c = 2; c <= 5; ++c) {
+            char name[32];
+            snprintf(name, sizeof name, "GPM_CLQ_KAPPA4_%d", c);
+            d.clq_kappa4[c - 2] = (int)env_i64(name, env_i64("GPM_CLQ_KAPPA4", d.clq_kappa4[c - 2]));
+        }
     }
     // GPM_NO_RCCL=1: per-GPU counts are summed on the host only (also lets two workers share one GPU in tests)
     if ((ngpus > 1 && env_i64("GPM_NO_RCCL", 0) == 0) || env_i64("GPM_FORCE_RCCL", 0)) {
@@ -2059,12 +2073,12 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CL
                     HIP_TRY(hipFuncSetAttribute((const void *)k_clq_build_lists<K, 16>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists));
                     k_clq_build_lists<K, 16><<<(unsigned)(nb * RB), 1024, lds_lists, s>>>(
-                        d.gv, list + b0, nb, dcap, RB, base_id, bm_words, d.clq_kappa4, sl.rows, stride, cnt);
+                        d.gv, list + b0, nb, dcap, RB, base_id, bm_words, d.clq_kappa4[c - 2], d.clq_probe, sl.rows, stride, cnt);
                 } else {
                     HIP_TRY(hipFuncSetAttribute((const void *)k_clq_build_lists<K, 4>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists));
                     k_clq_build_lists<K, 4><<<(unsigned)(nb * RB), 256, lds_lists, s>>>(
-                        d.gv, list + b0, nb, dcap, RB, base_id, bm_words, d.clq_kappa4, sl.rows, stride, cnt);
+                        d.gv, list + b0, nb, dcap, RB, base_id, bm_words, d.clq_kappa4[c - 2], d.clq_probe, sl.rows, stride, cnt);
                 }
             } else {
                 if (lds_build > 48 * 1024)
@@ -2081,12 +2095,12 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CL
                     HIP_TRY(hipFuncSetAttribute((const void *)k_clq_count4<2, 16>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
                     k_clq_count4<2, 16><<<(unsigned)(nb * phases * seg), 1024, lds_count, s>>>(d.gv, list + b0, nb, dcap,
-                                                                                                vt / 32, sl.rows, stride, cnt);
+                                                                                                vt / 32, d.count4_probe, sl.rows, stride, cnt);
                 } else {
                     HIP_TRY(hipFuncSetAttribute((const void *)k_clq_count4<4, 8>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
                     k_clq_count4<4, 8><<<(unsigned)(nb * phases * seg), 512, lds_count, s>>>(d.gv, list + b0, nb, dcap,
-                                                                                              vt / 32, sl.rows, stride, cnt);
+                                                                                              vt / 32, d.count4_probe, sl.rows, stride, cnt);
                 }
                 HIP_TRY(hipGetLastError());
                 if ((rc = timed_end(d, s))) return rc;

@@ -1779,8 +1779,10 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
 template <int K, int NW>
 __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, const int32_t *roots, int64_t nroots,
                                                                  int dcap, int RB, int32_t base_id, int bm_words,
-                                                                 int kappa4, uint32_t *rows_buf, int64_t stride_words,
-                                                                 unsigned long long *n_matches) {
+                                                                 int kappa4, int probe, uint32_t *rows_buf,
+                                                                 int64_t stride_words, unsigned long long *n_matches) {
+    // probe (a diagnostic, the counts are wrong with it): 1 = the lists are read and nothing is tested,
+    // 2 = the same with half of every list: what the delivery of the lists alone costs
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t s_wave_sum[NW];
     constexpr int NT = NW * GPM_WAVE;
@@ -1843,6 +1845,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
                 const int32_t v = U[i_l];
                 my_b = mid[v];
                 my_n = (int)(off[v + 1] - my_b);
+                if (probe == 2) my_n = (my_n + 1) / 2;
                 if (kappa4 >= 0 && (int64_t)(d - 1 - i_l) * kappa4 <= 4 * (int64_t)my_n) my_n = -1;
             }
         }
@@ -1921,7 +1924,12 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
                     }
                 }
             }
-            if (n > 0) {
+            if (n > 0 && probe) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int k = 0; k < CLQ_LIST_LOADS; ++k) x ^= (uint32_t)cur[k];
+                tri += x;
+            } else if (n > 0) {
                 uint32_t c[CLQ_LIST_LOADS], word[CLQ_LIST_LOADS];
 #pragma unroll
                 for (int k = 0; k < CLQ_LIST_LOADS; ++k) {
@@ -1938,6 +1946,10 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
                 for (int k = 0; k < 4; ++k) {
                     const int p = p0 + k * GPM_WAVE + lane;
                     c[k] = (uint32_t)((p < n ? adj[b + p] : u) - base_id);
+                }
+                if (probe) {
+                    tri += c[0] ^ c[1] ^ c[2] ^ c[3];
+                    continue;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) word[k] = bm[c[k] >> 5];
@@ -1959,6 +1971,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
             n = nn;
         }
     }
+    if (K != 3 && probe && tri == 0x12345678abcdULL) region[0] = 1;  // keeps the probe's loads alive
     if (K == 3) {
         tri = wave_sum_u64(tri);
         if (lane == 0 && tri) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)tri);
@@ -2004,8 +2017,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
 // use one list.
 template <int SEG, int NW>
 __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
-                                                    int vt_words, const uint32_t *rows_buf, int64_t stride_words,
-                                                    unsigned long long *n_matches) {
+                                                    int vt_words, int probe, const uint32_t *rows_buf,
+                                                    int64_t stride_words, unsigned long long *n_matches) {
+    // probe = 1 (a diagnostic, the counts are wrong with it): tiles are copied in and set bits listed, no
+    // rows are ANDed -- what everything but the ANDs costs
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // the wave number read as a scalar: row numbers, row addresses and loop tests then stay out of the vector unit
     const int tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid / GPM_WAVE);
@@ -2149,7 +2164,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
         }
         const int my_len = (int)(my_res ? all >> 16 : all & 0xffffu);
         wave_lds_sync();
-        if (all && lane_ok) {
+        if (all && lane_ok && !probe) {
             uint32_t acc = 0;
             int t = my_first;
             const uint16_t *jp = Jfirst;  // entry t of this block's list
@@ -2171,6 +2186,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
         C = C_n;
         i = inext;
     }
+    if (probe) total += J[lane];  // keeps the probe's lists alive
     total = wave_sum_u64(total);
     if (lane == 0 && total) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)total);
 }
