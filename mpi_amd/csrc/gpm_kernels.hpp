@@ -1781,8 +1781,9 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
                                                                  int dcap, int RB, int32_t base_id, int bm_words,
                                                                  int kappa4, int probe, uint32_t *rows_buf,
                                                                  int64_t stride_words, unsigned long long *n_matches) {
-    // probe (a diagnostic, the counts are wrong with it): 1 = the lists are read and nothing is tested,
-    // 2 = the same with half of every list: what the delivery of the lists alone costs
+    // probe (a diagnostic, the counts are wrong with it), bits: 1 = the lists are read and nothing is tested,
+    // 2 = the same with half of every list (what the delivery of the lists alone costs), 4 = rows that would be
+    // gathered from the hub matrix are left empty, 8 = no row is written out
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t s_wave_sum[NW];
     constexpr int NT = NW * GPM_WAVE;
@@ -1845,7 +1846,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
                 const int32_t v = U[i_l];
                 my_b = mid[v];
                 my_n = (int)(off[v + 1] - my_b);
-                if (probe == 2) my_n = (my_n + 1) / 2;
+                if (probe & 2) my_n = (my_n + 1) / 2;
                 if (kappa4 >= 0 && (int64_t)(d - 1 - i_l) * kappa4 <= 4 * (int64_t)my_n) my_n = -1;
             }
         }
@@ -1892,7 +1893,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
                     atomicOr(stage + (j >> 5), 1u << (j & 31));
                 }
             };
-            if (n < 0) {  // a row of few positions and a long list: one hub-matrix bit per position above it
+            if (n < 0 && !(probe & 4)) {  // a row of few positions and a long list: one hub-matrix bit per position above it
                 const uint32_t *hrow = g.hub + (size_t)(U[i] - g.hub_base) * (size_t)g.hub_wpr;
                 const int jfirst = ((i + 1) / (CLQ_GATHERS * GPM_WAVE)) * (CLQ_GATHERS * GPM_WAVE);
                 for (int j0 = jfirst; j0 < d; j0 += CLQ_GATHERS * GPM_WAVE) {
@@ -1924,7 +1925,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
                     }
                 }
             }
-            if (n > 0 && probe) {
+            if (n > 0 && (probe & 3)) {
                 uint32_t x = 0;
 #pragma unroll
                 for (int k = 0; k < CLQ_LIST_LOADS; ++k) x ^= (uint32_t)cur[k];
@@ -1947,7 +1948,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
                     const int p = p0 + k * GPM_WAVE + lane;
                     c[k] = (uint32_t)((p < n ? adj[b + p] : u) - base_id);
                 }
-                if (probe) {
+                if (probe & 3) {
                     tri += c[0] ^ c[1] ^ c[2] ^ c[3];
                     continue;
                 }
@@ -1957,7 +1958,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
                 for (int k = 0; k < 4; ++k)
                     if ((word[k] >> (c[k] & 31)) & 1u) hit(c[k], word[k]);
             }
-            if (K != 3) {
+            if (K != 3 && !(probe & 8)) {
                 wave_lds_sync();
                 for (int t = 0; t < T; ++t) {
                     const int Wt = big_words(d, t);
