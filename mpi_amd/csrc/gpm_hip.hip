@@ -193,7 +193,7 @@ struct DevState {
     int clq_lists_waves = 16;     // GPM_CLQ_LISTS_WAVES: waves per workgroup of that kernel (4 or 16)
     // GPM_CLQ_KAPPA4 (all classes) / GPM_CLQ_KAPPA4_<class 2..5>: a row of that kernel whose list has this many quarter
     // entries per position left to test is gathered from the hub matrix instead (-1: never)
-    int clq_kappa4[4] = {6, 6, 3, 3};  // the big universes gather more of their rows: measured per class on the headline graph
+    int clq_kappa4[4] = {6, 3, 3, 3};  // measured per class on the headline graph
     unsigned long long *clq_slots = nullptr;  // [0,CLQ_SLOTS) matches, [CLQ_SLOTS,2*CLQ_SLOTS) bytes
     // 4-cycle path: two-path count of every root, counter arrays (cyc_blocks of them for the workgroups of
     // the light kernel, then CYC_HEAVY_GROUPS groups of cyc_batch for heavy roots), root queues of the light
@@ -2069,7 +2069,7 @@ static int clique_launch_big(DevState &d, ChunkSlot &sl, const uint32_t n[CLQ_CL
                 // rows from the adjacency lists, tested against a bitmap of the universe in LDS
                 const int RB = d.clq_build_rb > 0 ? d.clq_build_rb : (c == 2 ? 1 : c == 3 ? 2 : c == 4 ? 4 : 8);
                 const int nwl = d.clq_lists_waves;
-                const size_t lds_lists = ((size_t)bm_words + bm_words / 4 + dcap + (size_t)nwl * 128) * sizeof(uint32_t);
+                const size_t lds_lists = ((size_t)bm_words + bm_words / 4 + 2 * (size_t)dcap + 256 + (size_t)nwl * 128) * sizeof(uint32_t);
                 if (nwl == 16) {
                     HIP_TRY(hipFuncSetAttribute((const void *)k_clq_build_lists<K, 16>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists));

@@ -1772,7 +1772,21 @@ __global__ __launch_bounds__(256) void k_clq_build(GraphView g, const int32_t *r
 // at least `kappa4` / 4 entries per position above it is gathered from the hub
 // matrix instead (every vertex of the launch's universes is a hub), one bit
 // per position; kappa4 < 0: never.
-// LDS (words): bitmap[bm_words] | prefix[bm_words / 4] (16-bit, one per word pair) | U[dcap] | stage[NW][128].
+// LDS (words): bitmap[bm_words] | prefix[bm_words / 4] (16-bit, one per word pair) | U[dcap] | G[dcap + 256] | stage[NW][128].
+// x with lane LANE replaced by the scalar value v
+template <int LANE>
+__device__ __forceinline__ uint32_t write_lane(uint32_t x, uint32_t v) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(x) : "s"(v), "n"(LANE));
+    return x;
+}
+
+// bit (v & 31) of word as one instruction: the bit-field extract takes its offset modulo 32
+__device__ __forceinline__ uint32_t bit_of_word(uint32_t word, uint32_t v) {
+    uint32_t h;
+    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(h) : "v"(word), "v"(v));
+    return h;
+}
+
 #define CLQ_BM_MAX_WORDS 16384  // ids a bitmap can cover: 2^19
 #define CLQ_LIST_LOADS 8        // list reads in flight per lane and row
 
@@ -1800,7 +1814,12 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
     uint32_t *bm = smem;                                                  // bm_words is a multiple of 1024
     uint16_t *prefix = reinterpret_cast<uint16_t *>(smem + bm_words);     // set bits before each pair of bitmap words
     int32_t *U = (int32_t *)(smem + bm_words + bm_words / 4);
-    uint32_t *stage = smem + bm_words + bm_words / 4 + dcap + wave * 128;
+    // G[j]: where the hub-matrix bit of column U[j] lies in a row: bit number (bits 0..4: a bit-field extract
+    // takes its offset from there) and byte offset of its word (from bit 5 up), worked out once per root for
+    // all the rows that are gathered.  G has dcap + 256 entries: the 256 after d stand for the root itself,
+    // so a gather past the universe reads a valid place (its bit is dropped).
+    uint32_t *G = smem + bm_words + bm_words / 4 + dcap;
+    uint32_t *stage = smem + bm_words + bm_words / 4 + 2 * dcap + CLQ_GATHERS * GPM_WAVE + wave * 128;
     for (int k = tid; k < bm_words / 4; k += NT) reinterpret_cast<uint4 *>(bm)[k] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     for (int i = tid; i < d; i += NT) {
@@ -1808,6 +1827,10 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
         U[i] = v;
         const uint32_t c = (uint32_t)(v - base_id);
         atomicOr(bm + (c >> 5), 1u << (c & 31));
+    }
+    for (int i = tid; i < d + CLQ_GATHERS * GPM_WAVE; i += NT) {  // a trip of gathers begins below d and reads 256 entries
+        const uint32_t h = (uint32_t)((i < d ? adj[ub + i] : u) - g.hub_base);
+        G[i] = ((h >> 5) << 7) | (h & 31u);
     }
     __syncthreads();
     {  // prefix counts: every thread sums its run of words, the runs are scanned, the words filled in
@@ -1833,7 +1856,8 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
 
     const int T = big_tiles(d);
     uint32_t *region = rows_buf + ri * stride_words;
-    uint64_t tri = 0;
+    uint64_t tri = 0;       // per lane
+    uint32_t tri_wave = 0;  // the same for every lane: bits counted from ballots
     const int step = NW * RB;              // distance between two rows of one wave
     const int first = rb + RB * wave;      // this wave's first row
     for (int i_batch = first; i_batch < d; i_batch += 64 * step) {
@@ -1894,35 +1918,47 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
                 }
             };
             if (n < 0 && !(probe & 4)) {  // a row of few positions and a long list: one hub-matrix bit per position above it
-                const uint32_t *hrow = g.hub + (size_t)(U[i] - g.hub_base) * (size_t)g.hub_wpr;
-                const int jfirst = ((i + 1) / (CLQ_GATHERS * GPM_WAVE)) * (CLQ_GATHERS * GPM_WAVE);
+                // The row's address is a scalar and a lane's place in it comes ready from G: a gather is one LDS
+                // read, one shift, one read of global memory, one bit-field extract and a compare.  Which
+                // positions count (above i, below d) is tested per lane, and only in a row's first and last
+                // trip; the ballots are scalars as they come, and the four masks of a trip go to the stage
+                // in one write.
+                const int32_t vi = __builtin_amdgcn_readfirstlane(U[i]);
+                const char *hrow = reinterpret_cast<const char *>(g.hub + (size_t)(vi - g.hub_base) * (size_t)g.hub_wpr);
+                const int jfirst = (i + 1) & ~(GPM_WAVE - 1);
                 for (int j0 = jfirst; j0 < d; j0 += CLQ_GATHERS * GPM_WAVE) {
-                    uint32_t word[CLQ_GATHERS], sh[CLQ_GATHERS];
-                    bool live[CLQ_GATHERS];
+                    uint32_t gx[CLQ_GATHERS], word[CLQ_GATHERS], bit[CLQ_GATHERS];
 #pragma unroll
-                    for (int k = 0; k < CLQ_GATHERS; ++k) {
-                        const int j = j0 + k * GPM_WAVE + lane;
-                        live[k] = j > i && j < d;
-                        word[k] = 0;
-                        sh[k] = 0;
-                        if (live[k]) {
-                            const uint32_t c = (uint32_t)(U[j] - g.hub_base);
-                            word[k] = hrow[c >> 5];
-                            sh[k] = c & 31;
+                    for (int k = 0; k < CLQ_GATHERS; ++k) gx[k] = G[j0 + k * GPM_WAVE + lane];
+                    // the lanes of the first 64 that lie at or below i read the row's first word instead of a scattered one
+                    if (j0 == jfirst && j0 + lane <= i) gx[0] = 0;
+#pragma unroll
+                    for (int k = 0; k < CLQ_GATHERS; ++k)
+                        word[k] = *reinterpret_cast<const uint32_t *>(hrow + (gx[k] >> 5));
+#pragma unroll
+                    for (int k = 0; k < CLQ_GATHERS; ++k) bit[k] = bit_of_word(word[k], gx[k]);
+                    if (j0 == jfirst || j0 + CLQ_GATHERS * GPM_WAVE > d) {
+#pragma unroll
+                        for (int k = 0; k < CLQ_GATHERS; ++k) {
+                            const int j = j0 + k * GPM_WAVE + lane;
+                            if (j <= i || j >= d) bit[k] = 0;
                         }
                     }
-#pragma unroll
-                    for (int k = 0; k < CLQ_GATHERS; ++k) {
-                        const int jb = j0 + k * GPM_WAVE;
-                        if (jb >= d) break;
-                        const bool bit = live[k] && ((word[k] >> sh[k]) & 1u);
-                        const unsigned long long mask = __ballot(bit);
-                        if (K == 3) tri += bit;
-                        if (K != 3 && lane == 0) {  // the stage has room for 4096 positions: jb + 63 < 4096
-                            stage[jb >> 5] = (uint32_t)mask;
-                            stage[(jb >> 5) + 1] = (uint32_t)(mask >> 32);
-                        }
-                    }
+                    uint32_t out = 0;  // lane l: word l of the eight the trip's masks fill
+                    const unsigned long long m0 = __ballot(bit[0] != 0u), m1 = __ballot(bit[1] != 0u),
+                                             m2 = __ballot(bit[2] != 0u), m3 = __ballot(bit[3] != 0u);
+                    static_assert(CLQ_GATHERS == 4, "four masks per trip");
+                    if (K == 3) tri_wave += (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+                    out = write_lane<0>(out, (uint32_t)m0);
+                    out = write_lane<1>(out, (uint32_t)(m0 >> 32));
+                    out = write_lane<2>(out, (uint32_t)m1);
+                    out = write_lane<3>(out, (uint32_t)(m1 >> 32));
+                    out = write_lane<4>(out, (uint32_t)m2);
+                    out = write_lane<5>(out, (uint32_t)(m2 >> 32));
+                    out = write_lane<6>(out, (uint32_t)m3);
+                    out = write_lane<7>(out, (uint32_t)(m3 >> 32));
+                    // the stage has room for 4096 positions; words past it would be zeros anyway
+                    if (K != 3 && lane < 2 * CLQ_GATHERS && (j0 >> 5) + lane < 128) stage[(j0 >> 5) + lane] = out;
                 }
             }
             if (n > 0 && (probe & 3)) {
@@ -1975,7 +2011,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
     if (K != 3 && probe && tri == 0x12345678abcdULL) region[0] = 1;  // keeps the probe's loads alive
     if (K == 3) {
         tri = wave_sum_u64(tri);
-        if (lane == 0 && tri) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)tri);
+        if (lane == 0 && tri + tri_wave) atomicAdd(n_matches + (blockIdx.x & (CLQ_SLOTS - 1)), (unsigned long long)(tri + tri_wave));
     }
 }
 
