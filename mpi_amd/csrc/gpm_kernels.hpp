@@ -1889,6 +1889,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
         for (int k = 0; k < CLQ_LIST_LOADS; ++k) {
             const int p = k * GPM_WAVE + lane;
             cur[k] = p < n ? adj[b + p] : u;
+            nxt[k] = u;
         }
         for (int r = 0; r < 64; ++r) {
             const int i = i_batch + r * step;
@@ -1896,10 +1897,12 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
             int64_t nb = 0;
             int nn = 0;
             if (r + 1 < 64 && i + step < d) range_of(r + 1, nb, nn);
+            if (nn > 0) {  // (a gathered or empty next row has nothing to ask for: one scalar branch instead of eight masked reads)
 #pragma unroll
-            for (int k = 0; k < CLQ_LIST_LOADS; ++k) {  // the next row's entries are in flight while this row is tested
-                const int p = k * GPM_WAVE + lane;
-                nxt[k] = p < nn ? adj[nb + p] : u;
+                for (int k = 0; k < CLQ_LIST_LOADS; ++k) {  // the next row's entries are in flight while this row is tested
+                    const int p = k * GPM_WAVE + lane;
+                    nxt[k] = p < nn ? adj[nb + p] : u;
+                }
             }
             if (K != 3) {
                 stage[lane] = 0;
