@@ -185,7 +185,7 @@ struct DevState {
     int count4_wide_min = 512;  // GPM_COUNT4_WIDE_MIN: tiles of at least this many columns are counted by 16 waves
     // Diagnostics that give wrong counts (a warning says so): GPM_CLQ_PROBE, bits: 1 the list kernel reads its lists and
     // tests nothing, 2 the same with half of every list, 4 no hub-matrix gathers, 8 no rows written;
-    // GPM_COUNT4_PROBE=1 the count kernel lists and ANDs nothing.
+    // GPM_COUNT4_PROBE bits: 1 the count kernel lists and ANDs nothing, 2 it writes no list entries either.
     int clq_probe = 0, count4_probe = 0;
     int clq_lists_max_class = 5;  // GPM_CLQ_LISTS_MAX_CLASS: size classes up to this one build their rows from the
                                   // adjacency lists, larger ones from hub-matrix gathers (1 = gathers only)

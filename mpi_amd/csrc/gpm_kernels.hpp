@@ -2059,8 +2059,9 @@ template <int SEG, int NW>
 __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const int32_t *roots, int64_t nroots, int dcap,
                                                     int vt_words, int probe, const uint32_t *rows_buf,
                                                     int64_t stride_words, unsigned long long *n_matches) {
-    // probe = 1 (a diagnostic, the counts are wrong with it): tiles are copied in and set bits listed, no
-    // rows are ANDed -- what everything but the ANDs costs
+    // probe (a diagnostic, the counts are wrong with it), bits: 1 = tiles are copied in and set bits listed, no
+    // rows are ANDed (what everything but the ANDs costs); 2 = the set bits are counted and scanned but no
+    // list entry is written (with 1: what the emission loops cost)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // the wave number read as a scalar: row numbers, row addresses and loop tests then stay out of the vector unit
     const int tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid / GPM_WAVE);
@@ -2184,6 +2185,7 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_count4(GraphView g, const
         uint16_t *at0 = J + ((incl - c) & 0xffffu), *at1 = J + VT - 1 - ((incl - c) >> 16);
         const uint32_t entry0 = pos0 << lg;
         uint32_t be = two ? bits & 0x5555u : bits, bo = two ? bits & 0xaaaau : 0u;
+        if (probe & 2) be = bo = 0;  // no entries written
         while (be) {
             const uint32_t b = (uint32_t)__builtin_ctz(be);
             be &= be - 1;
