@@ -1801,7 +1801,8 @@ __global__ __launch_bounds__(NW * GPM_WAVE) void k_clq_build_lists(GraphView g, 
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ uint32_t s_wave_sum[NW];
     constexpr int NT = NW * GPM_WAVE;
-    const int tid = threadIdx.x, lane = lane_id(), wave = tid / GPM_WAVE;
+    // the wave number read as a scalar: row numbers, list ranges and loop tests then stay out of the vector unit
+    const int tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid / GPM_WAVE);
     const int64_t ri = blockIdx.x / RB;
     const int rb = (int)(blockIdx.x % RB);
     if (ri >= nroots) return;
